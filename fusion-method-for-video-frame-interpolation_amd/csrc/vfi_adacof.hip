@@ -1,0 +1,295 @@
+// AdaCoF deformable sampling for gfx950.
+//
+//   vfi_adacof_forward : FunctionAdaCoF.forward (reference src/adacof/cupy_module/adacof.py:313-361,
+//                        kernel text :6-65)
+//   vfi_adacof_fused   : both sampling sides + occlusion blend + flow-variance mask of
+//                        AdaCoFNet.forward (reference src/fusion_net/fusion_adacofnet.py:195-213)
+//
+// Roofline: HBM.  Per output pixel the kernel streams F*F (w, alpha, beta) triples per side
+// (600 B/px for F=5, two sides) and writes 12..40 B; the frame gathers are served by L1/L2
+// (a wave touches a few rows of the frame).  Design:
+//   * one thread owns VEC=4 consecutive pixels, so every (w, alpha, beta) plane is read with
+//     16 B/lane (1 KiB per wave-instruction, fully coalesced), ONCE for all colour channels
+//     (the reference launches one thread per channel and re-reads the triple 3x);
+//   * a 64x4 thread block covers a 256x4 pixel tile; blocks are walked row-major so that the
+//     gathers of neighbouring blocks share L2 lines;
+//   * the replication pad of the reference is folded into the tap clamp (fused entry point), so
+//     no padded copy of the frame is ever materialised;
+//   * the flow-variance statistics reuse the same (w, alpha, beta) registers (one pass, pivoted
+//     second moments), so the mask costs no extra HBM traffic.
+#include "vfi_common.h"
+
+namespace {
+
+using vfi::ceil_div;
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+    float v[1];
+    __device__ __forceinline__ void load(const float *p) { v[0] = *p; }
+};
+template <>
+struct Vec<4> {
+    float v[4];
+    __device__ __forceinline__ void load(const float *p) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float *p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        p[0] = v[0];
+    }
+}
+
+// One tap of adacof.py:24-60 for C channels.  `row`/`col` already contain i + k*dilation (minus the
+// folded replication pad in the fused variant).  (int) is truncation toward zero; each tap index
+// is clamped on its own; the bilinear weights use the un-clamped fractions (may extrapolate).
+template <int C>
+__device__ __forceinline__ void tap_accumulate(const float *__restrict__ in, size_t plane, int Hin,
+                                               int Win, int row, int col, float w, float alpha,
+                                               float beta, float (&acc)[C]) {
+    const int A = (int)alpha;
+    const int B = (int)beta;
+    const float fa = alpha - (float)A;
+    const float fb = beta - (float)B;
+    const int i0 = min(max(row + A, 0), Hin - 1);
+    const int i1 = min(max(row + A + 1, 0), Hin - 1);
+    const int j0 = min(max(col + B, 0), Win - 1);
+    const int j1 = min(max(col + B + 1, 0), Win - 1);
+    const float ga = 1.0f - fa, gb = 1.0f - fb;
+    const float w00 = ga * gb, w10 = fa * gb, w01 = ga * fb, w11 = fa * fb;
+    const int o00 = i0 * Win + j0, o10 = i1 * Win + j0, o01 = i0 * Win + j1, o11 = i1 * Win + j1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float *p = in + (size_t)c * plane;
+        const float v = p[o00] * w00 + p[o10] * w10 + p[o01] * w01 + p[o11] * w11;
+        acc[c] += w * v;
+    }
+}
+
+// ---- plain forward ------------------------------------------------------------------------
+template <int C, int VEC>
+__global__ __launch_bounds__(256) void adacof_forward_kernel(
+    const float *__restrict__ input, const float *__restrict__ weight,
+    const float *__restrict__ offset_i, const float *__restrict__ offset_j,
+    float *__restrict__ output, int Ctot, int Hin, int Win, int H, int W, int F, int dil) {
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * VEC;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z / ceil_div(Ctot, C);
+    const int c0 = (blockIdx.z % ceil_div(Ctot, C)) * C;
+    if (x0 >= W || y >= H) return;
+    const size_t plane = (size_t)H * W;
+    const size_t in_plane = (size_t)Hin * Win;
+    const float *in = input + ((size_t)n * Ctot + c0) * in_plane;
+    const size_t pix = (size_t)y * W + x0;
+    const size_t tbase = (size_t)n * F * F * plane + pix;
+
+    float acc[VEC][C];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[v][c] = 0.0f;
+
+    for (int k = 0; k < F; ++k)
+        for (int l = 0; l < F; ++l) {
+            const size_t t = tbase + (size_t)(k * F + l) * plane;
+            Vec<VEC> w, a, b;
+            w.load(weight + t);
+            a.load(offset_i + t);
+            b.load(offset_j + t);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                tap_accumulate<C>(in, in_plane, Hin, Win, y + k * dil, x0 + v + l * dil, w.v[v],
+                                  a.v[v], b.v[v], acc[v]);
+        }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (c0 + c < Ctot) {
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = acc[v][c];
+            store_vec<VEC>(output + ((size_t)n * Ctot + c0 + c) * plane + pix, o);
+        }
+    }
+}
+
+// ---- fused: two sides + occlusion blend + flow-variance mask ---------------------------------
+struct FlowStats {  // pivoted weighted moments of one offset plane (alpha or beta)
+    float m, q;
+};
+
+template <int C, int VEC, int FT>
+__global__ __launch_bounds__(256) void adacof_fused_kernel(
+    const float *__restrict__ frame0, const float *__restrict__ frame2,
+    const float *__restrict__ w1, const float *__restrict__ a1, const float *__restrict__ b1,
+    const float *__restrict__ w2, const float *__restrict__ a2, const float *__restrict__ b2,
+    const float *__restrict__ occ, float *__restrict__ out_t1, float *__restrict__ out_t2,
+    float *__restrict__ out_frame, float *__restrict__ out_mask, int H, int W, int Frt, int dil) {
+    const int F = FT > 0 ? FT : Frt;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * VEC;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x0 >= W || y >= H) return;
+    const size_t plane = (size_t)H * W;
+    const size_t pix = (size_t)y * W + x0;
+    const size_t tbase = (size_t)n * F * F * plane + pix;
+    const int pad = ((F - 1) * dil) / 2;  // ReplicationPad2d(kernel_pad) folded into the clamp
+
+    float res[2][VEC][C];
+    float var[2][VEC];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const float *__restrict__ in = (side ? frame2 : frame0) + (size_t)n * C * plane;
+        const float *__restrict__ wp = side ? w2 : w1;
+        const float *__restrict__ ap = side ? a2 : a1;
+        const float *__restrict__ bp = side ? b2 : b1;
+        float s[VEC], pa[VEC], pb[VEC];
+        FlowStats sa[VEC], sb[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) res[side][v][c] = 0.0f;
+            s[v] = 0.0f;
+            sa[v] = {0.0f, 0.0f};
+            sb[v] = {0.0f, 0.0f};
+        }
+        {
+            Vec<VEC> a, b;  // pivot = offsets of tap 0 (keeps the second moments well conditioned)
+            a.load(ap + tbase);
+            b.load(bp + tbase);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { pa[v] = a.v[v]; pb[v] = b.v[v]; }
+        }
+#pragma unroll(FT > 0 ? FT : 1)
+        for (int k = 0; k < F; ++k) {
+#pragma unroll(FT > 0 ? FT : 1)
+            for (int l = 0; l < F; ++l) {
+                const size_t t = tbase + (size_t)(k * F + l) * plane;
+                Vec<VEC> w, a, b;
+                w.load(wp + t);
+                a.load(ap + t);
+                b.load(bp + t);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    tap_accumulate<C>(in, plane, H, W, y + k * dil - pad, x0 + v + l * dil - pad,
+                                      w.v[v], a.v[v], b.v[v], res[side][v]);
+                    const float da = a.v[v] - pa[v], db = b.v[v] - pb[v];
+                    s[v] += w.v[v];
+                    sa[v].m += w.v[v] * da;
+                    sa[v].q += w.v[v] * da * da;
+                    sb[v].m += w.v[v] * db;
+                    sb[v].q += w.v[v] * db * db;
+                }
+            }
+        }
+        // Var = sum_k W (Mean - x)^2 with Mean = sum_k W x   (fusion_adacofnet.py:204-208),
+        // evaluated from moments pivoted at x_p: x = x' + x_p, c = x_p (S - 1):
+        //   Var = M'^2 (S - 2) + Q' + 2 c M' (S - 1) + c^2 S
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float S = s[v];
+            const float ca = pa[v] * (S - 1.0f), cb = pb[v] * (S - 1.0f);
+            const float va = sa[v].m * sa[v].m * (S - 2.0f) + sa[v].q + 2.0f * ca * sa[v].m * (S - 1.0f) + ca * ca * S;
+            const float vb = sb[v].m * sb[v].m * (S - 2.0f) + sb[v].q + 2.0f * cb * sb[v].m * (S - 1.0f) + cb * cb * S;
+            var[side][v] = va + vb;
+        }
+    }
+
+    Vec<VEC> o;
+    o.load(occ + (size_t)n * plane + pix);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t q = ((size_t)n * C + c) * plane + pix;
+        float f[VEC], t1[VEC], t2[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            t1[v] = res[0][v][c];
+            t2[v] = res[1][v][c];
+            f[v] = o.v[v] * t1[v] + (1.0f - o.v[v]) * t2[v];  // fusion_adacofnet.py:198
+        }
+        store_vec<VEC>(out_frame + q, f);
+        if (out_t1) store_vec<VEC>(out_t1 + q, t1);
+        if (out_t2) store_vec<VEC>(out_t2 + q, t2);
+    }
+    if (out_mask) {
+        float m[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float mx = fmaxf(var[0][v], var[1][v]);
+            m[v] = fminf(fmaxf(mx, 0.0f), 20.0f) / 20.0f;  // fusion_adacofnet.py:211-212
+        }
+        store_vec<VEC>(out_mask + (size_t)n * plane + pix, m);
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int vfi_adacof_forward(const float *input, const float *weight, const float *offset_i,
+                                  const float *offset_j, float *output, int N, int C, int Hin,
+                                  int Win, int H, int W, int F, int dilation, vfi_stream_t stream) {
+    VFI_REQUIRE(input && weight && offset_i && offset_j && output, VFI_ERR_INVALID_ARG,
+                "vfi_adacof_forward: null pointer");
+    VFI_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && F > 0 && dilation > 0, VFI_ERR_INVALID_ARG,
+                "vfi_adacof_forward: non-positive size");
+    // adacof.py:326-327
+    VFI_REQUIRE(Hin - ((F - 1) * dilation + 1) == H - 1 && Win - ((F - 1) * dilation + 1) == W - 1,
+                VFI_ERR_SHAPE, "vfi_adacof_forward: input %dx%d does not match output %dx%d for F=%d dilation=%d",
+                Hin, Win, H, W, F, dilation);
+    VFI_REQUIRE((long long)Hin * Win < (1ll << 31) && (long long)N * F * F * H * W < (1ll << 40),
+                VFI_ERR_UNSUPPORTED, "vfi_adacof_forward: tensor too large");
+    const bool vec = (W % 4 == 0) && aligned16(weight) && aligned16(offset_i) && aligned16(offset_j) &&
+                     aligned16(output);
+    hipStream_t s = vfi::as_stream(stream);
+    const int ct = (C % 3 == 0) ? 3 : 1;  // channels per thread
+    dim3 block(64, 4);
+    dim3 grid(vfi::ceil_div(W, 64 * (vec ? 4 : 1)), vfi::ceil_div(H, 4), N * vfi::ceil_div(C, ct));
+    VFI_REQUIRE(grid.z <= 65535 && grid.y <= 65535, VFI_ERR_UNSUPPORTED, "vfi_adacof_forward: grid too large");
+#define LAUNCH(CT, VEC)                                                                         \
+    hipLaunchKernelGGL((adacof_forward_kernel<CT, VEC>), grid, block, 0, s, input, weight, offset_i, \
+                       offset_j, output, C, Hin, Win, H, W, F, dilation)
+    if (ct == 3) { if (vec) LAUNCH(3, 4); else LAUNCH(3, 1); }
+    else         { if (vec) LAUNCH(1, 4); else LAUNCH(1, 1); }
+#undef LAUNCH
+    return vfi::check_launch("vfi_adacof_forward");
+}
+
+extern "C" int vfi_adacof_fused(const float *frame0, const float *frame2, const float *w1,
+                                const float *a1, const float *b1, const float *w2, const float *a2,
+                                const float *b2, const float *occ, float *out_t1, float *out_t2,
+                                float *out_frame, float *out_mask, int N, int C, int H, int W, int F,
+                                int dilation, vfi_stream_t stream) {
+    VFI_REQUIRE(frame0 && frame2 && w1 && a1 && b1 && w2 && a2 && b2 && occ && out_frame,
+                VFI_ERR_INVALID_ARG, "vfi_adacof_fused: null pointer");
+    VFI_REQUIRE(N > 0 && H > 0 && W > 0 && F > 0 && dilation > 0, VFI_ERR_INVALID_ARG,
+                "vfi_adacof_fused: non-positive size");
+    VFI_REQUIRE(C == 3, VFI_ERR_UNSUPPORTED, "vfi_adacof_fused: C=%d (only 3 colour channels)", C);
+    VFI_REQUIRE(((F - 1) * dilation) % 2 == 0, VFI_ERR_SHAPE,
+                "vfi_adacof_fused: (F-1)*dilation must be even (F=%d dilation=%d)", F, dilation);
+    VFI_REQUIRE((long long)H * W < (1ll << 31), VFI_ERR_UNSUPPORTED, "vfi_adacof_fused: frame too large");
+    bool vec = (W % 4 == 0) && aligned16(occ) && aligned16(out_frame);
+    for (const void *p : {(const void *)w1, (const void *)a1, (const void *)b1, (const void *)w2,
+                          (const void *)a2, (const void *)b2})
+        vec = vec && aligned16(p);
+    for (const void *p : {(const void *)out_t1, (const void *)out_t2, (const void *)out_mask})
+        vec = vec && (p == nullptr || aligned16(p));
+    hipStream_t s = vfi::as_stream(stream);
+    dim3 block(64, 4);
+    dim3 grid(vfi::ceil_div(W, 64 * (vec ? 4 : 1)), vfi::ceil_div(H, 4), N);
+    VFI_REQUIRE(grid.z <= 65535 && grid.y <= 65535, VFI_ERR_UNSUPPORTED, "vfi_adacof_fused: grid too large");
+#define LAUNCH(VEC, FT)                                                                            \
+    hipLaunchKernelGGL((adacof_fused_kernel<3, VEC, FT>), grid, block, 0, s, frame0, frame2, w1, a1, b1, \
+                       w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, H, W, F, dilation)
+    if (F == 5) { if (vec) LAUNCH(4, 5); else LAUNCH(1, 5); }
+    else        { if (vec) LAUNCH(4, 0); else LAUNCH(1, 0); }
+#undef LAUNCH
+    return vfi::check_launch("vfi_adacof_fused");
+}

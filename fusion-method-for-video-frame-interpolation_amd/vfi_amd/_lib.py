@@ -1,0 +1,92 @@
+"""ctypes binding of libvfi_hip.so (include/vfi_hip.h).  Loads lazily, fails loudly."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libvfi_hip.so"
+
+c_f = ctypes.c_void_p   # device pointers travel as plain addresses
+c_i = ctypes.c_int
+c_d = ctypes.c_double
+c_s = ctypes.c_void_p   # hipStream_t
+
+
+class VfiLibraryError(RuntimeError):
+    """The HIP library is missing / failed, or a tensor is not usable by it."""
+
+
+# name -> argtypes.  tests/test_abi.py checks this table against include/vfi_hip.h.
+SIGNATURES = {
+    "vfi_adacof_forward": [c_f] * 5 + [c_i] * 8 + [c_s],
+    "vfi_adacof_fused": [c_f] * 13 + [c_i] * 6 + [c_s],
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def library_path():
+    return os.environ.get("VFI_HIP_LIBRARY", os.path.join(_HERE, _LIB_NAME))
+
+
+def lib():
+    """Returns the loaded library; raises VfiLibraryError if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  (loads the process's HIP runtime first so both share it)
+        path = library_path()
+        if not os.path.exists(path):
+            raise VfiLibraryError(
+                f"{path} not found: build it with `make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}` "
+                "(or __graft_entry__.build()).  vfi_amd has no CPU fallback.")
+        try:
+            handle = ctypes.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise VfiLibraryError(f"cannot load {path}: {e}") from e
+        handle.vfi_abi_version.restype = c_i
+        handle.vfi_status_string.restype = ctypes.c_char_p
+        handle.vfi_status_string.argtypes = [c_i]
+        handle.vfi_last_error.restype = ctypes.c_char_p
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                raise VfiLibraryError(f"{path} does not export {name}")
+            fn.argtypes = argtypes
+            fn.restype = c_i
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        h = lib()
+        raise VfiLibraryError(
+            f"{what}: {h.vfi_status_string(status).decode()} ({status}): {h.vfi_last_error().decode()}")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dptr(t, name="tensor", dtype=None):
+    """Device address of a dense HIP tensor (None -> NULL)."""
+    import torch
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise VfiLibraryError(f"{name} must be a tensor on a HIP device (vfi_amd has no CPU path)")
+    if t.dtype != (dtype or torch.float32):
+        raise VfiLibraryError(f"{name} must be {dtype or torch.float32}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise VfiLibraryError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,87 @@
+/*
+ * vfi_hip.h -- C ABI of libvfi_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame inference hot path of "Fusion Method for Video Frame Interpolation":
+ * steerable-pyramid phase decomposition + PhaseNet, AdaCoF deformable sampling and
+ * the FusionNet blend.
+ *
+ * Conventions (every entry point):
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - Returns VFI_OK (0) or a negative vfi_status; never throws, never exits.
+ *     vfi_status_string() names a code, vfi_last_error() gives the detail of the last
+ *     failure on the calling thread.
+ *   - Every data pointer is a DEVICE pointer owned by the caller (the Python host passes
+ *     torch-allocated HBM); tensors are dense fp32, NCHW unless stated otherwise.
+ *   - `stream` is a hipStream_t passed as void* (the host passes torch's current HIP
+ *     stream).  Calls only enqueue work; none synchronises the device, allocates or
+ *     frees device memory, so a sequence of calls can be captured into a hipGraph.
+ *     Workspace is caller-provided or owned by an explicit plan object.
+ *   - The library holds no global mutable state besides immutable per-plan tables.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the
+ * reference repository root).
+ */
+#ifndef VFI_HIP_H
+#define VFI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFI_ABI_VERSION 1
+
+typedef void *vfi_stream_t; /* hipStream_t */
+
+typedef enum vfi_status {
+    VFI_OK = 0,
+    VFI_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, unsupported value */
+    VFI_ERR_SHAPE = -2,       /* shape relation violated (mirrors the reference's asserts) */
+    VFI_ERR_LAUNCH = -3,      /* HIP launch / runtime error */
+    VFI_ERR_UNSUPPORTED = -4, /* valid request this build has no kernel for */
+    VFI_ERR_FFT = -5,         /* hipFFT plan / exec failure */
+    VFI_ERR_NOMEM = -6        /* host or device allocation failed (plan creation only) */
+} vfi_status;
+
+int vfi_abi_version(void);
+const char *vfi_status_string(int status);
+const char *vfi_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * AdaCoF deformable sampling
+ * ---------------------------------------------------------------------------------- */
+
+/* Replaces FunctionAdaCoF.forward + kernel_AdaCoF_updateOutput
+ * (src/adacof/cupy_module/adacof.py:313-361 and :6-65).
+ *   input    (N, C, Hin, Win)   already padded by the caller, as in the reference
+ *   weight, offset_i, offset_j  (N, F*F, H, W)
+ *   output   (N, C, H, W)
+ * Shape relation of adacof.py:326-327 is enforced: Hin - ((F-1)*dilation + 1) == H - 1
+ * (same for W), otherwise VFI_ERR_SHAPE.  Sampling semantics are the reference's:
+ * (int) truncation of the offsets, each of the four taps clamped to the input
+ * independently, bilinear weights from the un-clamped fractional parts. */
+int vfi_adacof_forward(const float *input, const float *weight, const float *offset_i,
+                       const float *offset_j, float *output, int N, int C, int Hin, int Win,
+                       int H, int W, int F, int dilation, vfi_stream_t stream);
+
+/* One fused pass over both sampling sides of AdaCoFNet.forward
+ * (src/fusion_net/fusion_adacofnet.py:195-213; plain variant src/adacof/models/adacofnet.py:195-199):
+ *   t1 = AdaCoF(ReplicationPad(frame0), W1, A1, B1);  t2 = AdaCoF(ReplicationPad(frame2), W2, A2, B2)
+ *   frame1 = Occ * t1 + (1 - Occ) * t2
+ *   mask   = clip(max(sum Var(W1; A1, B1), sum Var(W2; A2, B2)), 0, 20) / 20
+ * The replication pad of (F-1)*dilation/2 pixels is folded into the tap clamp, so
+ * frame0/frame2 are the UN-padded (N, C, H, W) frames.  w*, a*, b* are (N, F*F, H, W),
+ * occ is (N, 1, H, W).  out_t1 / out_t2 / out_mask may be NULL (not produced);
+ * out_frame is required.  (F-1)*dilation must be even (as in the reference, where
+ * kernel_pad = int((F-1)*dilation/2)). */
+int vfi_adacof_fused(const float *frame0, const float *frame2,
+                     const float *w1, const float *a1, const float *b1,
+                     const float *w2, const float *a2, const float *b2, const float *occ,
+                     float *out_t1, float *out_t2, float *out_frame, float *out_mask,
+                     int N, int C, int H, int W, int F, int dilation, vfi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFI_HIP_H */

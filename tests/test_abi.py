@@ -1,0 +1,66 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/vfi_hip.h declares, and the ctypes table binds exactly those symbols."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+import vfi_amd
+from vfi_amd import _lib
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "vfi_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vfi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    h = vfi_amd.lib()
+    assert h.vfi_abi_version() == 1
+    names = _declared()
+    assert "vfi_adacof_forward" in names and "vfi_adacof_fused" in names
+    raw = ctypes.CDLL(vfi_amd.library_path())
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/vfi_hip.h but not exported"
+
+
+def test_ctypes_table_matches_header():
+    declared = set(_declared()) - {"vfi_abi_version", "vfi_status_string", "vfi_last_error"}
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+
+
+def test_header_argument_counts_match_ctypes_table():
+    text = open(os.path.join(ROOT, "include", "vfi_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, argtypes in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
+        assert m, name
+        nargs = len([a for a in m.group(1).split(",") if a.strip()])
+        assert nargs == len(argtypes), (name, nargs, len(argtypes))
+
+
+def test_status_strings():
+    h = vfi_amd.lib()
+    assert h.vfi_status_string(0) == b"VFI_OK"
+    assert h.vfi_status_string(-2) == b"VFI_ERR_SHAPE"
+
+
+def test_argument_validation_needs_no_gpu():
+    # Null pointers / bad shapes are rejected before anything touches a device.
+    h = vfi_amd.lib()
+    assert h.vfi_adacof_forward(None, None, None, None, None, 1, 3, 8, 8, 4, 4, 5, 1, None) == -1
+    one = ctypes.c_void_p(16)
+    assert h.vfi_adacof_forward(one, one, one, one, one, 1, 3, 9, 8, 4, 4, 5, 1, None) == -2
+    assert b"does not match" in h.vfi_last_error()
+
+
+def test_no_cpu_fallback():
+    import pytest
+    import torch
+    from vfi_amd.adacof.cupy_module.adacof import FunctionAdaCoF
+    x = torch.zeros(1, 3, 8, 8)
+    w = torch.zeros(1, 25, 4, 4)
+    with pytest.raises(NotImplementedError):   # reference adacof.py:356-357
+        FunctionAdaCoF.apply(x, w, w, w, 1)
