@@ -139,7 +139,147 @@ def gen_adacof():
              dilation=dil, output=out)
 
 
-GENERATORS = {"adacof": gen_adacof}
+# ----------------------------------------------------------------------------------------
+# Networks: the reference's own classes loaded with the oracle's SEEDED weights (the trained
+# AdaCoF checkpoint is not in the reference snapshot, and trained weights are not committed);
+# fixtures hold inputs + the reference's outputs only.
+# ----------------------------------------------------------------------------------------
+def _oracle():
+    root = os.path.dirname(os.path.dirname(HERE))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import nets_cpu, synth
+    return nets_cpu, synth
+
+
+def _flat(prefix, vals):
+    d = {prefix + "high": vals.high_level.numpy(), prefix + "low": vals.low_level.numpy()}
+    for k, (p, a) in enumerate(zip(vals.phase, vals.amplitude)):
+        d[f"{prefix}phase{k}"] = p.numpy()
+        d[f"{prefix}amp{k}"] = a.numpy()
+    return d
+
+
+def _sub(prefix, vals, step):
+    """Strided subsample + per-tensor sums of a DecompValues (keeps big fixtures small)."""
+    d = {}
+    items = [("high", vals.high_level), ("low", vals.low_level)]
+    items += [(f"phase{k}", p) for k, p in enumerate(vals.phase)] + [(f"amp{k}", a) for k, a in enumerate(vals.amplitude)]
+    for name, t in items:
+        d[prefix + name] = t[..., ::step, ::step].numpy()
+        d[prefix + name + "_sum"] = t.double().sum(dim=(1, 2, 3)).numpy()
+    return d
+
+
+def gen_phasenet():
+    """Inputs come from oracle.synth.synthetic_vals(seed,...) and are NOT stored."""
+    _placeholders()
+    nets, synth = _oracle()
+    from src.phase_net.phase_net import PhaseNet
+    from src.train import utils as rutils
+    from src.train.pyramid import DecompValues as RefVals
+    for tag, (h, w, step) in {"32x48": (32, 48, 1), "96x112": (96, 112, 3)}.items():
+        height = int(np.ceil((np.log2(min(h, w)) - 3) * 2) + 2)          # utils.py:168-171
+        pyr = types.SimpleNamespace(height=height, nbands=4)
+        net = PhaseNet(pyr, torch.device("cpu"), num_img=2)
+        print(net.load_state_dict(nets.phasenet_random_state_dict(seed=1)))
+        net.eval()
+        vals_batch = RefVals(*synth.synthetic_vals(h + w, 6, h, w, height))
+        vals_list = rutils.separate_vals(vals_batch, 2)                   # utils.py:83-127
+        vals_in = rutils.get_concat_layers_inf(pyr, vals_list)            # utils.py:47-80
+        with torch.no_grad():
+            normed = net.normalize_vals(vals_in)
+            out = net(normed)
+        d = dict(h=h, w=w, height=height, weight_seed=1, input_seed=h + w, step=step)
+        d.update(_sub("out_", out, step))
+        if step == 1:
+            d.update(_flat("norm_", normed))
+        d["max_low"] = net.max_low_level.numpy()
+        for k, mx in enumerate(net.max_amplitudes):
+            d[f"max_amp{k}"] = mx.numpy()
+        save("phasenet_" + tag, **d)
+
+
+def gen_layout():
+    """Pins separate_vals / get_concat_layers_inf / get_last|first_value_levels / subtract_values
+    on an integer-coded pyramid (every element carries its own (img, band, level, y, x) code)."""
+    _placeholders()
+    from src.train import utils as rutils
+    from src.train.pyramid import DecompValues
+    _, synth = _oracle()
+    h, w, height = 16, 24, 6
+    bands, low = synth.level_sizes(h, w, height)
+    code = lambda n, a, b, base: (base + torch.arange(n * a * b, dtype=torch.float32).reshape(n, 1, a, b))
+    vals = DecompValues(high_level=code(6, h, w, 1e5), low_level=code(6, *low, 2e5),
+                        phase=[code(24, a, b, 1e6 * (k + 1)) for k, (a, b) in enumerate(bands)],
+                        amplitude=[code(24, a, b, -1e6 * (k + 1)) for k, (a, b) in enumerate(bands)])
+    pyr = types.SimpleNamespace(height=height, nbands=4)
+    lst = rutils.separate_vals(vals, 2)
+    cat = rutils.get_concat_layers_inf(pyr, lst)
+    last = rutils.get_last_value_levels(lst[0], use_levels=1)
+    first = rutils.get_first_value_levels(lst[1], use_levels=2)
+    sub = rutils.subtract_values(lst[0], lst[1])
+    d = dict(h=h, w=w, height=height)
+    d.update(_flat("vals_", vals)); d.update(_flat("sep0_", lst[0])); d.update(_flat("sep1_", lst[1]))
+    d.update(_flat("cat_", cat)); d.update(_flat("last_", last)); d.update(_flat("first_", first))
+    d.update(_flat("sub_", sub))
+    save("layout_helpers", **d)
+
+
+def gen_fusionnet():
+    _placeholders()
+    nets, _ = _oracle()
+    from src.fusion_net.fusion_net import FusionNet
+    net = FusionNet()
+    print(net.load_state_dict(nets.fusionnet_random_state_dict(seed=2)))
+    net.eval()
+    for tag, (h, w) in {"64x64": (64, 64), "40x72": (40, 72)}.items():
+        rng = np.random.default_rng(h * w)
+        r = lambda c: torch.from_numpy(rng.random((1, c, h, w), dtype=np.float32))
+        base, ada, ph, other, maps = r(3), r(3), r(3), r(6), r(3)
+        with torch.no_grad():
+            o0 = net(base, ada, ph, other, maps, variant=0)
+            o1 = net(base, ada, ph, other, maps, variant=1)
+        save("fusionnet_" + tag, seed=2, base=base.numpy(), adacof=ada.numpy(), phase=ph.numpy(),
+             other=other.numpy(), maps=maps.numpy(), out_variant0=o0.numpy(), out_variant1=o1.numpy())
+
+
+def gen_adacofnet():
+    """KernelEstimation heads + the AdaCoFNet glue (pad to /32, normalise, flow-variance mask, crop)
+    with the sampling call replaced by the value the fixture `adacof` pins (oracle C)."""
+    _placeholders()
+    nets, _ = _oracle()
+    from oracle import adacof_cpu
+    from src.fusion_net import fusion_adacofnet as ref
+
+    class Sampler:
+        @staticmethod
+        def apply(inp, wgt, a, b, dil):
+            return torch.from_numpy(adacof_cpu.adacof_forward(inp.numpy(), wgt.contiguous().numpy(),
+                                                             a.contiguous().numpy(), b.contiguous().numpy(), dil))
+    args = types.SimpleNamespace(kernel_size=5, dilation=1, gpu_id=0)
+    net = ref.AdaCoFNet(args)
+    net.moduleAdaCoF = Sampler.apply          # the CUDA-only op (adacof.py:356-357 raises on CPU)
+    print(net.load_state_dict(nets.adacofnet_random_state_dict(seed=3)))
+    net.eval()
+    for tag, (h, w) in {"64x96": (64, 96), "40x50": (40, 50)}.items():
+        rng = np.random.default_rng(h + 3 * w)
+        f0 = torch.from_numpy(rng.random((1, 3, h, w), dtype=np.float32))
+        f2 = torch.from_numpy(rng.random((1, 3, h, w), dtype=np.float32))
+        with torch.no_grad():
+            t1, t2, fr, mask = net(f0, f2)
+            d = dict(seed=3, frame0=f0.numpy(), frame2=f2.numpy(), t1=t1.numpy(), t2=t2.numpy(),
+                     frame1=fr.numpy(), mask=mask.numpy())
+            if h % 32 == 0 and w % 32 == 0:
+                heads = net.get_kernel(ref.moduleNormalize(f0), ref.moduleNormalize(f2))
+                for name, t in zip(("w1", "a1", "b1", "w2", "a2", "b2", "occ"), heads):
+                    d["head_" + name] = t[..., ::4, ::4].numpy()      # strided subsample
+                    d["head_" + name + "_sum"] = t.double().sum(dim=(2, 3)).numpy()
+        save("adacofnet_" + tag, **d)
+
+
+GENERATORS = {"adacof": gen_adacof, "phasenet": gen_phasenet, "layout": gen_layout,
+              "fusionnet": gen_fusionnet, "adacofnet": gen_adacofnet}
 
 
 def main():
