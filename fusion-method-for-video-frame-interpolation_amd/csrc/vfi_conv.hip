@@ -1,0 +1,294 @@
+// Dense 2-D convolution (stride 1, "same" size, zero or reflect padding) on the gfx950 matrix cores,
+// exact fp32 (v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate; there is no xf32 on gfx950).
+//
+// Replaces the cuDNN convolutions behind the reference's three networks:
+//   PhaseNetBlock            reference src/phase_net/phase_net.py:190-207   (1x1 / 3x3 reflect, BN folded, ELU/tanh)
+//   KernelEstimation         reference src/fusion_net/fusion_adacofnet.py:18-107 (3x3 zero pad, ReLU/sigmoid)
+//   FusionNet                reference src/fusion_net/fusion_net.py:24-41    (5x5 / 3x3 / 1x1 reflect, ReLU)
+//
+// Roofline: MFMA fp32 (157.3 TFLOP/s dense).  Direct (implicit-GEMM) formulation per workgroup:
+//   D[cout][pixel] += sum_{cin,ky,kx} Wt[cout][(cin,ky,kx)] * X[(cin,ky,kx)][pixel]
+//   * M = 32 output channels, N = 32 consecutive pixels of one output row, K = 2 input channels
+//     of the same tap per MFMA (lanes 0-31 hold k = 0, lanes 32-63 hold k = 1);
+//   * a 256-thread workgroup (4 waves, one per SIMD) owns an 8-row x 32-column output tile for
+//     BN = 32*NT output channels; each wave owns 2 rows x BN channels = 2*NT independent 32x32
+//     accumulators, so the 64-cycle MFMA issues back to back;
+//   * the K loop walks the input channels in chunks of CK; a chunk's input tile (with its KS-1
+//     halo, padding resolved while loading) and weight slab are staged global -> registers -> LDS,
+//     double buffered, one barrier per chunk; the loads of chunk c+1 are in flight during the
+//     MFMAs of chunk c;
+//   * every LDS fragment read is one ds_read_b32 whose 32-lane groups touch 32 consecutive dwords
+//     (conflict free); tap / channel offsets are compile-time immediates;
+//   * accumulator layout puts the pixel on the lane and the channel on the register, so each
+//     epilogue store instruction writes two full 128-B row segments of the NCHW output;
+//   * bias, activation (ReLU / ELU / tanh / sigmoid) and an optional residual add are fused into
+//     the epilogue; batch strides are explicit so inputs / outputs may be channel slices of larger
+//     (concatenated) tensors without a copy.
+#include "vfi_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct ConvArgs {
+    const float *x;      // (N, Cin, H, W) slice, batch stride x_bs
+    const float *wp;     // packed weights [Cin_pad][KS*KS][Cout_pad]
+    const float *bias;   // (Cout) or null
+    const float *res;    // residual (N, Cout, H, W) slice, batch stride res_bs, or null
+    float *y;            // (N, Cout, H, W) slice, batch stride y_bs
+    long long x_bs, res_bs, y_bs;
+    int Cin, Cin_pad, Cout, Cout_pad, H, W, tiles_x;
+    int pad_mode;  // 0 zero, 1 reflect
+    int act;       // vfi_act
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case 1: return fmaxf(v, 0.0f);
+        case 2: return v > 0.0f ? v : expm1f(v);
+        case 3: return tanhf(v);
+        case 4: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ int reflect_index(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return min(max(i, 0), n - 1);  // tile overhang beyond the reflected range feeds discarded outputs only
+}
+
+template <int KS, int CK, int NT>
+struct ConvTile {
+    static constexpr int TH = 8, TW = 32, PADK = (KS - 1) / 2;
+    static constexpr int R = TH + KS - 1, PW = TW + KS - 1, PLANE = R * PW, TAPS = KS * KS, BN = 32 * NT;
+    static constexpr int IN_ELEMS = CK * PLANE;
+    static constexpr int W_ELEMS = CK * TAPS * BN;
+    static constexpr int IN_PER_THREAD = (IN_ELEMS + 255) / 256;
+    static constexpr int W4_PER_THREAD = (W_ELEMS / 4 + 255) / 256;
+    static constexpr int BUF = IN_ELEMS + W_ELEMS;
+    static constexpr size_t LDS_BYTES = 2ull * BUF * sizeof(float);
+};
+
+template <int KS, int CK, int NT>
+__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
+    using T = ConvTile<KS, CK, NT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+    const int nb = blockIdx.y, n = blockIdx.z;
+    const int x0 = tile_x * T::TW, y0 = tile_y * T::TH;
+    const int HW = a.H * a.W;
+
+    // ---- per-thread staging map (identical for every chunk) -------------------------------------
+    int in_off[T::IN_PER_THREAD];   // offset inside the chunk's channel block, or -1 (zero fill)
+    int in_c[T::IN_PER_THREAD];     // channel inside the chunk (for the Cin tail)
+#pragma unroll
+    for (int i = 0; i < T::IN_PER_THREAD; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / T::PLANE, rem = e % T::PLANE;
+        const int r = rem / T::PW, xx = rem % T::PW;
+        int gy = y0 - T::PADK + r, gx = x0 - T::PADK + xx;
+        bool ok = e < T::IN_ELEMS;
+        if (a.pad_mode == 1) {
+            gy = reflect_index(gy, a.H);
+            gx = reflect_index(gx, a.W);
+        } else {
+            ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        }
+        in_off[i] = ok ? c * HW + gy * a.W + gx : -1;
+        in_c[i] = c;
+    }
+    const float *xn = a.x + (size_t)n * a.x_bs;
+    const float *wn = a.wp + (size_t)nb * T::BN;
+
+    float in_reg[T::IN_PER_THREAD];
+    float4 w_reg[T::W4_PER_THREAD];
+
+    auto load_chunk = [&](int ch) {
+        const float *xc = xn + (size_t)ch * CK * HW;
+        const int cbase = ch * CK;
+#pragma unroll
+        for (int i = 0; i < T::IN_PER_THREAD; ++i) {
+            const bool ok = in_off[i] >= 0 && (cbase + in_c[i]) < a.Cin;
+            in_reg[i] = ok ? xc[in_off[i]] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < T::W4_PER_THREAD; ++i) {
+            const int f = tid + 256 * i;
+            if (T::W_ELEMS / 4 % 256 == 0 || f < T::W_ELEMS / 4) {
+                const int row = f / (T::BN / 4), col4 = f % (T::BN / 4);
+                w_reg[i] = *reinterpret_cast<const float4 *>(
+                    wn + ((size_t)ch * CK * T::TAPS + row) * a.Cout_pad + col4 * 4);
+            }
+        }
+    };
+    auto store_chunk = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < T::IN_PER_THREAD; ++i) {
+            const int e = tid + 256 * i;
+            if (T::IN_ELEMS % 256 == 0 || e < T::IN_ELEMS) buf[e] = in_reg[i];
+        }
+        float4 *wb = reinterpret_cast<float4 *>(buf + T::IN_ELEMS);
+#pragma unroll
+        for (int i = 0; i < T::W4_PER_THREAD; ++i) {
+            const int f = tid + 256 * i;
+            if (T::W_ELEMS / 4 % 256 == 0 || f < T::W_ELEMS / 4) wb[f] = w_reg[i];
+        }
+    };
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nt][rr][q] = 0.0f;
+
+    const int nchunks = a.Cin_pad / CK;
+    load_chunk(0);
+    store_chunk(lds);
+    __syncthreads();
+
+    const int b_base = khalf * T::PLANE + (2 * wave) * T::PW + l31;
+    const int a_base = khalf * T::TAPS * T::BN + l31;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float *buf = lds + (ch & 1) * T::BUF;
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        const float *in_s = buf + b_base;
+        const float *w_s = buf + T::IN_ELEMS + a_base;
+#pragma unroll
+        for (int c2 = 0; c2 < CK / 2; ++c2) {
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    float bf[2], af[NT];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) bf[rr] = in_s[2 * c2 * T::PLANE + (rr + ky) * T::PW + kx];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        af[nt] = w_s[(2 * c2 * T::TAPS + ky * KS + kx) * T::BN + nt * 32];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr)
+                            acc[nt][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[nt], bf[rr], acc[nt][rr], 0, 0, 0);
+                }
+            }
+        }
+        if (ch + 1 < nchunks) store_chunk(lds + ((ch + 1) & 1) * T::BUF);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + activation (+ residual), 128-B row segments per store ------------------
+    const int gx = x0 + l31;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int gy = y0 + 2 * wave + rr;
+        if (gy >= a.H || gx >= a.W) continue;
+        const size_t pix = (size_t)gy * a.W + gx;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = nb * T::BN + nt * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+                if (co < a.Cout) {
+                    float v = acc[nt][rr][q];
+                    if (a.bias) v += a.bias[co];
+                    v = apply_act(v, a.act);
+                    const size_t o = (size_t)co * HW + pix;
+                    if (a.res) v += a.res[(size_t)n * a.res_bs + o];
+                    a.y[(size_t)n * a.y_bs + o] = v;
+                }
+            }
+        }
+    }
+}
+
+// OIHW -> [Cin_pad][KS*KS][Cout_pad] with optional per-output-channel scale (folded BatchNorm).
+__global__ void conv2d_pack_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                   float *__restrict__ out, int Cout, int Cin, int taps, int Cin_pad,
+                                   int Cout_pad) {
+    const size_t total = (size_t)Cin_pad * taps * Cout_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = i % Cout_pad;
+        const int t = (i / Cout_pad) % taps;
+        const int ci = i / ((size_t)Cout_pad * taps);
+        float v = 0.0f;
+        if (co < Cout && ci < Cin) {
+            v = w[((size_t)co * Cin + ci) * taps + t];
+            if (scale) v *= scale[co];
+        }
+        out[i] = v;
+    }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int KS, int CK, int NT>
+int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
+    using T = ConvTile<KS, CK, NT>;
+    static bool attr_done = false;  // idempotent; racing threads set the same value
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_mfma_kernel<KS, CK, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+        if (e != hipSuccess) return vfi::fail(VFI_ERR_LAUNCH, "vfi_conv2d: set LDS size: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int tiles_y = vfi::ceil_div(a.H, T::TH);
+    dim3 grid(a.tiles_x * tiles_y, a.Cout_pad / T::BN, N);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, CK, NT>), grid, dim3(256), T::LDS_BYTES, s, a);
+    return vfi::check_launch("vfi_conv2d");
+}
+
+}  // namespace
+
+extern "C" long long vfi_conv2d_packed_floats(int Cout, int Cin, int KS) {
+    if (Cout <= 0 || Cin <= 0 || KS <= 0) return -1;
+    return (long long)round_up(Cin, 8) * KS * KS * round_up(Cout, 32);
+}
+
+extern "C" int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin,
+                               int KS, vfi_stream_t stream) {
+    VFI_REQUIRE(w_oihw && packed, VFI_ERR_INVALID_ARG, "vfi_conv2d_pack: null pointer");
+    VFI_REQUIRE(Cout > 0 && Cin > 0 && (KS == 1 || KS == 3 || KS == 5), VFI_ERR_INVALID_ARG,
+                "vfi_conv2d_pack: bad shape Cout=%d Cin=%d KS=%d", Cout, Cin, KS);
+    const long long total = vfi_conv2d_packed_floats(Cout, Cin, KS);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv2d_pack_kernel, dim3(blocks), dim3(256), 0, vfi::as_stream(stream), w_oihw, scale,
+                       packed, Cout, Cin, KS * KS, round_up(Cin, 8), round_up(Cout, 32));
+    return vfi::check_launch("vfi_conv2d_pack");
+}
+
+extern "C" int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,
+                          const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
+                          int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream) {
+    VFI_REQUIRE(x && packed_w && y, VFI_ERR_INVALID_ARG, "vfi_conv2d: null pointer");
+    VFI_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, VFI_ERR_INVALID_ARG, "vfi_conv2d: non-positive size");
+    VFI_REQUIRE(KS == 1 || KS == 3 || KS == 5, VFI_ERR_UNSUPPORTED, "vfi_conv2d: kernel size %d", KS);
+    VFI_REQUIRE(pad_mode == 0 || pad_mode == 1, VFI_ERR_INVALID_ARG, "vfi_conv2d: pad_mode %d", pad_mode);
+    VFI_REQUIRE(act >= 0 && act <= 4, VFI_ERR_INVALID_ARG, "vfi_conv2d: act %d", act);
+    // torch's reflect padding requires pad < size
+    VFI_REQUIRE(pad_mode == 0 || ((KS - 1) / 2 < H && (KS - 1) / 2 < W), VFI_ERR_SHAPE,
+                "vfi_conv2d: reflect padding %d needs a larger input than %dx%d", (KS - 1) / 2, H, W);
+    VFI_REQUIRE((long long)Cin * H * W < (1ll << 31) && (long long)Cout * H * W < (1ll << 31), VFI_ERR_UNSUPPORTED,
+                "vfi_conv2d: per-sample tensor too large for 32-bit offsets");
+    VFI_REQUIRE(N <= 65535, VFI_ERR_UNSUPPORTED, "vfi_conv2d: batch %d", N);
+    ConvArgs a;
+    a.x = x; a.wp = packed_w; a.bias = bias; a.res = residual; a.y = y;
+    a.x_bs = x_bstride; a.res_bs = res_bstride; a.y_bs = y_bstride;
+    a.Cin = Cin; a.Cin_pad = round_up(Cin, 8); a.Cout = Cout; a.Cout_pad = round_up(Cout, 32);
+    a.H = H; a.W = W; a.tiles_x = vfi::ceil_div(W, 32);
+    a.pad_mode = pad_mode; a.act = act;
+    hipStream_t s = vfi::as_stream(stream);
+    const bool wide = (a.Cout_pad % 64 == 0);
+    if (KS == 3) return wide ? launch_conv<3, 8, 2>(a, N, s) : launch_conv<3, 8, 1>(a, N, s);
+    if (KS == 5) return wide ? launch_conv<5, 4, 2>(a, N, s) : launch_conv<5, 4, 1>(a, N, s);
+    return wide ? launch_conv<1, 8, 2>(a, N, s) : launch_conv<1, 8, 1>(a, N, s);
+}

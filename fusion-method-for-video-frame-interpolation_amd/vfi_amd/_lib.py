@@ -10,6 +10,7 @@ c_f = ctypes.c_void_p   # device pointers travel as plain addresses
 c_i = ctypes.c_int
 c_d = ctypes.c_double
 c_s = ctypes.c_void_p   # hipStream_t
+c_l = ctypes.c_longlong
 
 
 class VfiLibraryError(RuntimeError):
@@ -20,7 +21,12 @@ class VfiLibraryError(RuntimeError):
 SIGNATURES = {
     "vfi_adacof_forward": [c_f] * 5 + [c_i] * 8 + [c_s],
     "vfi_adacof_fused": [c_f] * 13 + [c_i] * 6 + [c_s],
+    "vfi_conv2d_packed_floats": [c_i] * 3,
+    "vfi_conv2d_pack": [c_f] * 3 + [c_i] * 3 + [c_s],
+    "vfi_conv2d": [c_f, c_l, c_f, c_f, c_f, c_l, c_f, c_l] + [c_i] * 8 + [c_s],
 }
+# entry points that return a value instead of a vfi_status
+RESTYPES = {"vfi_conv2d_packed_floats": c_l}
 
 _lock = threading.Lock()
 _lib = None
@@ -57,7 +63,7 @@ def lib():
             if fn is None:
                 raise VfiLibraryError(f"{path} does not export {name}")
             fn.argtypes = argtypes
-            fn.restype = c_i
+            fn.restype = RESTYPES.get(name, c_i)
         _lib = handle
     return _lib
 

@@ -81,6 +81,42 @@ int vfi_adacof_fused(const float *frame0, const float *frame2,
                      float *out_t1, float *out_t2, float *out_frame, float *out_mask,
                      int N, int C, int H, int W, int F, int dilation, vfi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Dense convolution on the fp32 matrix cores (exact fp32, v_mfma_f32_32x32x2_f32)
+ * ---------------------------------------------------------------------------------- */
+
+typedef enum vfi_act {
+    VFI_ACT_NONE = 0,
+    VFI_ACT_RELU = 1,
+    VFI_ACT_ELU = 2, /* alpha = 1 */
+    VFI_ACT_TANH = 3,
+    VFI_ACT_SIGMOID = 4
+} vfi_act;
+
+typedef enum vfi_pad { VFI_PAD_ZERO = 0, VFI_PAD_REFLECT = 1 } vfi_pad;
+
+/* Number of floats of the packed weight buffer for an (Cout, Cin, KS, KS) filter bank
+ * (layout [round_up(Cin,8)][KS*KS][round_up(Cout,32)], zero filled); -1 on bad arguments. */
+long long vfi_conv2d_packed_floats(int Cout, int Cin, int KS);
+
+/* Packs torch-layout (Cout, Cin, KS, KS) weights once at model-load time.  `scale` (Cout) or NULL
+ * multiplies each output channel (BatchNorm2d in eval mode folded into the preceding conv:
+ * reference src/phase_net/phase_net.py:191-193). */
+int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin, int KS,
+                    vfi_stream_t stream);
+
+/* y = act(conv2d(x, w) + bias) (+ residual): stride 1, padding (KS-1)/2 in `pad_mode`, KS in {1,3,5}.
+ * Replaces every nn.Conv2d (+ following BatchNorm / ReLU / ELU / Tanh / Sigmoid, + the additive U-Net
+ * skip) on the path: reference src/phase_net/phase_net.py:190-200, src/fusion_net/fusion_adacofnet.py:18-155,
+ * src/fusion_net/fusion_net.py:24-41,56-69.
+ *   x        (N, Cin, H, W); consecutive samples are x_bstride floats apart, so x may be a channel
+ *            slice of a wider tensor (no concat / split copies)
+ *   residual NULL or (N, Cout, H, W) with stride res_bstride, added AFTER the activation
+ *   y        (N, Cout, H, W) with stride y_bstride */
+int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,
+               const float *residual, long long res_bstride, float *y, long long y_bstride, int N, int Cin,
+               int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

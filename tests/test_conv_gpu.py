@@ -1,0 +1,113 @@
+"""GPU parity of the fp32-MFMA convolution (through the C ABI) against a plain PyTorch fp32
+CPU reference of the same op (the op the oracle networks are built from)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vfi_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b, ks, pad_mode, act, res=None, bn=None):
+    p = (ks - 1) // 2
+    if p and pad_mode == "reflect":
+        y = F.conv2d(F.pad(x, (p,) * 4, mode="reflect"), w, b)
+    else:
+        y = F.conv2d(x, w, b, padding=p)
+    if bn is not None:
+        g, beta, mean, var, eps = bn
+        y = F.batch_norm(y, mean, var, g, beta, training=False, eps=eps)
+    y = {None: lambda t: t, "relu": F.relu, "elu": F.elu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act](y)
+    return y if res is None else y + res
+
+
+CASES = [
+    # n, cin, cout, h, w, ks, pad, act
+    (1, 6, 32, 24, 40, 3, "zeros", "relu"),       # KernelEstimation first layer (Cin tail 6 -> 8)
+    (2, 32, 64, 17, 33, 3, "zeros", "relu"),      # ragged tile edges, batch 2
+    (1, 64, 25, 16, 32, 3, "zeros", None),        # head output (Cout tail 25 -> 32)
+    (1, 25, 25, 19, 21, 3, "zeros", None),
+    (1, 64, 1, 16, 16, 3, "zeros", "sigmoid"),    # occlusion head
+    (3, 88, 64, 23, 31, 3, "reflect", "elu"),     # PhaseNet 3x3 reflect block, batch = colour
+    (3, 81, 64, 9, 15, 1, "reflect", "elu"),      # PhaseNet 1x1 block
+    (3, 64, 8, 9, 15, 1, "zeros", "tanh"),        # prediction map
+    (1, 2, 64, 5, 7, 1, "zeros", "elu"),          # PhaseNet block 0 on the low residual
+    (1, 18, 32, 24, 40, 5, "reflect", "relu"),    # FusionNet encoder 5x5
+    (1, 128, 64, 12, 20, 5, "reflect", None),     # FusionNet decoder 5x5
+    (1, 32, 3, 24, 40, 1, "zeros", None),
+    (1, 128, 128, 10, 12, 3, "reflect", None),    # bottleneck
+    (1, 256, 512, 8, 8, 3, "zeros", "relu"),      # deep U-Net level, many chunks
+    (1, 3, 64, 3, 3, 3, "reflect", None),         # tiny image, smaller than one tile
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,ks,pad,act", CASES)
+def test_conv_matches_torch_cpu(n, cin, cout, h, w, ks, pad, act, device):
+    g = torch.Generator().manual_seed(cin * 1000 + cout + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wgt = torch.randn((cout, cin, ks, ks), generator=g) / (cin * ks * ks) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    ref = _ref(x, wgt, b, ks, pad, act)
+    pc = ops.PackedConv(wgt, b, device=device)
+    out = ops.conv2d(x.to(device), pc, pad, act)
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 2e-5, err
+
+
+def test_conv_bn_fold_residual_and_channel_slices(device):
+    g = torch.Generator().manual_seed(0)
+    n, h, w = 2, 20, 36
+    wide = torch.randn((n, 100, h, w), generator=g)
+    x = wide[:, 10:74]                                     # 64-channel slice of a wider tensor
+    wgt = torch.randn((64, 64, 3, 3), generator=g) / 24
+    b = torch.randn((64,), generator=g) * 0.1
+    bn = (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1,
+          torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5, 1e-5)
+    res = torch.randn((n, 64, h, w), generator=g)
+    ref = _ref(x, wgt, b, 3, "reflect", "elu", res=res, bn=bn)
+    pc = ops.PackedConv(wgt, b, bn=bn, device=device)
+    dwide = wide.to(device)
+    dout = torch.zeros((n, 96, h, w), device=device)
+    ops.conv2d(dwide[:, 10:74], pc, "reflect", "elu", residual=res.to(device), out=dout[:, 16:80])
+    torch.cuda.synchronize()
+    assert (dout[:, 16:80].cpu() - ref).abs().max().item() <= 3e-5
+    assert dout[:, :16].abs().max().item() == 0 and dout[:, 80:].abs().max().item() == 0
+
+
+def test_conv_is_exact_on_integer_data(device):
+    # fp32 MFMA is an exact fp32 fma chain: small-integer data must give the exact integer result
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(-3, 4, (1, 16, 16, 40), generator=g).float()
+    wgt = torch.randint(-2, 3, (32, 16, 3, 3), generator=g).float()
+    ref = F.conv2d(x, wgt, None, padding=1)
+    out = ops.conv2d(x.to(device), ops.PackedConv(wgt, None, device=device), "zeros", None)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_conv_full_size_linearity_720p(device):
+    # BASELINE-size property (no CPU oracle): conv(a*x1 + x2) == a*conv(x1) + conv(x2) (bias-free)
+    g = torch.Generator().manual_seed(2)
+    h, w = 736, 1280
+    x1 = torch.randn((1, 32, h, w), generator=g).to(device)
+    x2 = torch.randn((1, 32, h, w), generator=g).to(device)
+    wgt = torch.randn((32, 32, 3, 3), generator=g) / 17
+    pc = ops.PackedConv(wgt, None, device=device)
+    y1, y2 = ops.conv2d(x1, pc), ops.conv2d(x2, pc)
+    y12 = ops.conv2d(2.0 * x1 + x2, pc)
+    assert (y12 - (2.0 * y1 + y2)).abs().max().item() <= 5e-5
+    # and a window of the full-size launch against the CPU reference
+    ref = F.conv2d(x1[:, :, 100:140, 200:300].cpu(), wgt, None, padding=1)
+    assert (y1[:, :, 101:139, 201:299].cpu() - ref[:, :, 1:-1, 1:-1]).abs().max().item() <= 2e-5
+
+
+def test_conv_argument_errors(device):
+    pc = ops.PackedConv(torch.zeros(8, 4, 3, 3), None, device=device)
+    with pytest.raises(ops.VfiLibraryError):
+        ops.conv2d(torch.zeros(1, 5, 8, 8, device=device), pc)          # channel mismatch
+    with pytest.raises(ops.VfiLibraryError):
+        ops.conv2d(torch.zeros(1, 4, 8, 8), pc)                         # CPU tensor: no fallback
+    with pytest.raises(ops.VfiLibraryError):
+        ops.conv2d(torch.zeros(1, 4, 1, 8, device=device), pc, "reflect")  # reflect pad >= size
