@@ -11,6 +11,7 @@ c_i = ctypes.c_int
 c_d = ctypes.c_double
 c_s = ctypes.c_void_p   # hipStream_t
 c_l = ctypes.c_longlong
+c_fl = ctypes.c_float
 
 
 class VfiLibraryError(RuntimeError):
@@ -24,6 +25,15 @@ SIGNATURES = {
     "vfi_conv2d_packed_floats": [c_i] * 3,
     "vfi_conv2d_pack": [c_f] * 3 + [c_i] * 3 + [c_s],
     "vfi_conv2d": [c_f, c_l, c_f, c_f, c_f, c_l, c_f, c_l] + [c_i] * 8 + [c_s],
+    "vfi_adacof_prepare": [c_f] * 5 + [c_i] * 5 + [c_s],
+    "vfi_pool2": [c_f, c_l, c_f, c_l] + [c_i] * 5 + [c_s],
+    "vfi_resize_bilinear": [c_f, c_l, c_f, c_l, c_f, c_l] + [c_i] * 8 + [c_s],
+    "vfi_softmax_channels": [c_f, c_l, c_f, c_l] + [c_i] * 3 + [c_s],
+    "vfi_affine_slice": [c_f, c_l, c_f, c_l, c_i, c_l, c_f, c_fl, c_s],
+    "vfi_batch_max": [c_f, c_l, c_i, c_l, c_fl, c_f, c_f, c_s],
+    "vfi_phasenet_emit": [c_f, c_l, c_f, c_l, c_f, c_f, c_f, c_i, c_i, c_s],
+    "vfi_phasenet_emit_low": [c_f, c_l, c_f, c_l, c_f, c_f, c_i, c_i, c_s],
+    "vfi_tanh_residual_clamp": [c_f, c_f, c_f, c_l, c_s],
 }
 # entry points that return a value instead of a vfi_status
 RESTYPES = {"vfi_conv2d_packed_floats": c_l}

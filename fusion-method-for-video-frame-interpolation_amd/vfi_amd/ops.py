@@ -84,3 +84,75 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None):
     _lib.call("vfi_conv2d", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), rp, rs, yp, ys,
               n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], _lib.stream_ptr())
     return out
+
+
+def adacof_prepare(frame0, frame2):
+    """-> (pad0, pad2 (N,3,Hp,Wp), x6 (N,6,Hp,Wp)); Hp, Wp = sizes rounded up to multiples of 32."""
+    n, c, h, w = frame0.shape
+    if c != 3 or tuple(frame2.shape) != tuple(frame0.shape):
+        raise VfiLibraryError("adacof_prepare: frames must both be (N,3,H,W)")
+    hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    pad0, pad2, x6 = new((n, 3, hp, wp), frame0), new((n, 3, hp, wp), frame0), new((n, 6, hp, wp), frame0)
+    _lib.call("vfi_adacof_prepare", _lib.dptr(frame0, "frame0"), _lib.dptr(frame2, "frame2"), pad0.data_ptr(),
+              pad2.data_ptr(), x6.data_ptr(), n, h, w, hp, wp, _lib.stream_ptr())
+    return pad0, pad2, x6
+
+
+def pool2(x, is_max, out=None):
+    n, c, h, w = x.shape
+    if out is None:
+        out = new((n, c, h // 2, w // 2), x)
+    xp, xs = _slice_ptr(x, "x")
+    yp, ys = _slice_ptr(out, "out")
+    _lib.call("vfi_pool2", xp, xs, yp, ys, n, c, h, w, int(bool(is_max)), _lib.stream_ptr())
+    return out
+
+
+def resize_bilinear(x, size, align_corners, relu_input=False, residual=None, out=None):
+    n, c, h, w = x.shape
+    ho, wo = size
+    if out is None:
+        out = new((n, c, ho, wo), x)
+    xp, xs = _slice_ptr(x, "x")
+    yp, ys = _slice_ptr(out, "out")
+    rp, rs = (None, 0) if residual is None else _slice_ptr(residual, "residual")
+    _lib.call("vfi_resize_bilinear", xp, xs, rp, rs, yp, ys, n, c, h, w, ho, wo, int(bool(align_corners)),
+              int(bool(relu_input)), _lib.stream_ptr())
+    return out
+
+
+def softmax_channels_(x):
+    n, c, h, w = x.shape
+    xp, xs = _slice_ptr(x, "x")
+    _lib.call("vfi_softmax_channels", xp, xs, xp, xs, n, c, h * w, _lib.stream_ptr())
+    return x
+
+
+def affine_slice(src, dst, div=None, mul=1.0):
+    """dst[n] = src[n] / div[n] * mul over the per-sample (C,H,W) block (dst may be a channel slice)."""
+    n = src.shape[0]
+    count = src[0].numel()
+    if dst.shape[0] != n or dst[0].numel() != count:
+        raise VfiLibraryError("affine_slice: shape mismatch")
+    sp, ss = _slice_ptr(src, "src")
+    dp, ds = _slice_ptr(dst, "dst")
+    _lib.call("vfi_affine_slice", sp, ss, dp, ds, n, count, _lib.dptr(div, "div") if div is not None else None,
+              float(mul), _lib.stream_ptr())
+    return dst
+
+
+def batch_max(x, eps):
+    """max over each sample's (C,H,W) block, + eps -> (N,) tensor."""
+    n = x.shape[0]
+    xp, xs = _slice_ptr(x, "x")
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    ws = torch.empty(n, dtype=torch.int32, device=x.device)
+    _lib.call("vfi_batch_max", xp, xs, n, x[0].numel(), float(eps), out.data_ptr(), ws.data_ptr(), _lib.stream_ptr())
+    return out
+
+
+def tanh_residual_clamp(x, base):
+    out = torch.empty_like(x)
+    _lib.call("vfi_tanh_residual_clamp", _lib.dptr(x, "x"), _lib.dptr(base, "base"), out.data_ptr(), x.numel(),
+              _lib.stream_ptr())
+    return out

@@ -117,6 +117,58 @@ int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const
                const float *residual, long long res_bstride, float *y, long long y_bstride, int N, int Cin,
                int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Glue between the convolutions (HBM-bound; batch strides as for vfi_conv2d)
+ * ---------------------------------------------------------------------------------- */
+
+/* AdaCoFNet.forward prologue (src/fusion_net/fusion_adacofnet.py:182-193, src/adacof/utility.py:86-87):
+ * reflect-pads both (N,3,H,W) frames at the bottom/right to (Hp,Wp) (multiples of 32), writes the padded
+ * raw frames pad0/pad2 (N,3,Hp,Wp) for the sampler and x6 = cat(pad0 - mean, pad2 - mean) (N,6,Hp,Wp). */
+int vfi_adacof_prepare(const float *frame0, const float *frame2, float *pad0, float *pad2, float *x6, int N,
+                       int H, int W, int Hp, int Wp, vfi_stream_t stream);
+
+/* 2x2 / stride-2 pooling, floor output size.  is_max=0: AvgPool2d (fusion_adacofnet.py:76-89);
+ * is_max=1: MaxPool2d (src/fusion_net/fusion_net.py:41,59). */
+int vfi_pool2(const float *x, long long x_bstride, float *y, long long y_bstride, int N, int C, int H, int W,
+              int is_max, vfi_stream_t stream);
+
+/* torch bilinear interpolation to (Hout,Wout): align_corners=1 is nn.Upsample(scale_factor=2,
+ * align_corners=True) of fusion_adacofnet.py:30,42,54,68; align_corners=0 is nn.Upsample(size) of
+ * src/phase_net/phase_net.py:138-139 and nn.Upsample(scale_factor=2) of fusion_net.py:42.
+ * relu_input=1 applies ReLU to the source first and residual (NULL or (N,C,Hout,Wout)) is added
+ * to the result: `deconvolution(relu(x)) + s` of fusion_net.py:65-66 in one pass. */
+int vfi_resize_bilinear(const float *x, long long x_bstride, const float *residual, long long res_bstride,
+                        float *y, long long y_bstride, int N, int C, int Hin, int Win, int Hout, int Wout,
+                        int align_corners, int relu_input, vfi_stream_t stream);
+
+/* Softmax over the channel axis of (N,C,HW) (Subnet_weight, fusion_adacofnet.py:56).  In place allowed. */
+int vfi_softmax_channels(const float *x, long long x_bstride, float *y, long long y_bstride, int N, int C, int HW,
+                         vfi_stream_t stream);
+
+/* dst[n][e] = src[n][e] / div_per_sample[n] * mul for e < count (div_per_sample may be NULL).
+ * Slice copies into concat buffers; phase/pi and amplitude/max of PhaseNet.normalize_vals
+ * (src/phase_net/phase_net.py:61-70). */
+int vfi_affine_slice(const float *src, long long src_bstride, float *dst, long long dst_bstride, int N,
+                     long long count, const float *div_per_sample, float mul, vfi_stream_t stream);
+
+/* out_max[n] = max(x[n][0..count)) + eps (phase_net.py:55,69).  workspace_u32: N 32-bit words. */
+int vfi_batch_max(const float *x, long long x_bstride, int N, long long count, float eps, float *out_max,
+                  void *workspace_u32, vfi_stream_t stream);
+
+/* PhaseNet per-level outputs (phase_net.py:155-168 + reverse_normalize :80-90), pred (N,8,HW) from the
+ * block's tanh head, amp_in (N,8,HW) the normalised input amplitudes:
+ *   phase_out (N,4,HW) = pred[:,0:4]*pi ; amp_out (N,4,HW) = (b*amp_in[:,4:8] + (1-b)*amp_in[:,0:4])*max_amp[n],
+ *   b = (pred[:,4:8]+1)/2. */
+int vfi_phasenet_emit(const float *pred, long long pred_bstride, const float *amp_in, long long amp_bstride,
+                      const float *max_amp, float *phase_out, float *amp_out, int N, int HW, vfi_stream_t stream);
+
+/* phase_net.py:113-116 + :96-98: low_out (N,HW) = (a*low_in[:,0] + (1-a)*low_in[:,1])*max_low[n], a = (pred+1)/2. */
+int vfi_phasenet_emit_low(const float *pred, long long pred_bstride, const float *low_in, long long low_bstride,
+                          const float *max_low, float *low_out, int N, int HW, vfi_stream_t stream);
+
+/* FusionNet tail (fusion_net.py:70-77): y = clamp(base + tanh(x), 0, 1) over `count` floats. */
+int vfi_tanh_residual_clamp(const float *x, const float *base, float *y, long long count, vfi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

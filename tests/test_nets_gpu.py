@@ -1,0 +1,116 @@
+"""GPU parity of the three networks (host mirrors over the C ABI) against the fixtures produced by the
+reference's own classes, and against the oracle at a second size."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import layout_cpu, nets_cpu, synth
+from vfi_amd.fusion_net.fusion_adacofnet import AdaCoFNet
+from vfi_amd.fusion_net.fusion_net import FusionNet
+from vfi_amd.phase_net.phase_net import PhaseNet
+from vfi_amd.values import DecompValues
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerance: identical arithmetic in a different summation order (MFMA k-order vs oneDNN), over
+# <= 4608-term dot products of O(1) values; errors stay ~1e-6, bound stated generously.
+TOL = 3e-5
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.mark.parametrize("tag", ["64x64", "40x72"])
+def test_fusionnet_matches_reference_fixture(tag, device):
+    g = _load("fusionnet_" + tag)
+    net = FusionNet().to(device)
+    net.load_state_dict(nets_cpu.fusionnet_random_state_dict(int(g["seed"])))
+    net.eval()
+    t = lambda k: torch.from_numpy(g[k]).to(device)
+    for variant in (0, 1):
+        out = net(t("base"), t("adacof"), t("phase"), t("other"), t("maps"), variant=variant)
+        assert np.abs(out.cpu().numpy() - g[f"out_variant{variant}"]).max() <= TOL
+
+
+@pytest.mark.parametrize("tag", ["64x96", "40x50"])
+def test_adacofnet_matches_reference_fixture(tag, device):
+    g = _load("adacofnet_" + tag)
+    args = types.SimpleNamespace(kernel_size=5, dilation=1, gpu_id=0)
+    net = AdaCoFNet(args).to(device)
+    net.load_state_dict(nets_cpu.adacofnet_random_state_dict(int(g["seed"])))
+    net.eval()
+    f0, f2 = torch.from_numpy(g["frame0"]).to(device), torch.from_numpy(g["frame2"]).to(device)
+    t1, t2, fr, mask = net(f0, f2)
+    if tag == "64x96":  # no width padding -> t1 is comparable (see fusion_adacofnet.py:225)
+        np.testing.assert_allclose(t1.cpu().numpy(), g["t1"], atol=TOL)
+    np.testing.assert_allclose(t2.cpu().numpy(), g["t2"], atol=TOL)
+    np.testing.assert_allclose(fr.cpu().numpy(), g["frame1"], atol=TOL)
+    np.testing.assert_allclose(mask.cpu().numpy(), g["mask"], atol=1e-4)
+    if "head_w1" in g:
+        mean = torch.tensor(nets_cpu.CHANNEL_MEANS, device=device).view(1, 3, 1, 1)
+        heads = net.get_kernel(f0 - mean, f2 - mean)
+        for name, h in zip(("w1", "a1", "b1", "w2", "a2", "b2", "occ"), heads):
+            np.testing.assert_allclose(h[..., ::4, ::4].cpu().numpy(), g["head_" + name], atol=TOL)
+
+
+def _phasenet_inputs(g):
+    h, w, height = int(g["h"]), int(g["w"]), int(g["height"])
+    batch = synth.synthetic_vals(int(g["input_seed"]), 6, h, w, height)
+    vin = layout_cpu.get_concat_layers_inf(layout_cpu.separate_vals(batch, 2))
+    return height, vin
+
+
+@pytest.mark.parametrize("tag", ["32x48", "96x112"])
+def test_phasenet_matches_reference_fixture(tag, device):
+    g = _load("phasenet_" + tag)
+    step = int(g["step"])
+    height, vin = _phasenet_inputs(g)
+    pyr = types.SimpleNamespace(height=height, nbands=4)
+    net = PhaseNet(pyr, device)
+    net.load_state_dict(nets_cpu.phasenet_random_state_dict(int(g["weight_seed"])))
+    net.eval()
+    dv = DecompValues(vin.high_level.to(device), [p.to(device) for p in vin.phase],
+                      [a.to(device) for a in vin.amplitude], vin.low_level.to(device))
+    normed = net.normalize_vals(dv)
+    out = net(normed)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(net.max_low_level.cpu().numpy(), g["max_low"], rtol=1e-6)
+    for k, mx in enumerate(net.max_amplitudes):
+        np.testing.assert_allclose(mx.cpu().numpy(), g[f"max_amp{k}"], rtol=1e-6)
+    if step == 1:
+        for k in range(len(normed.phase)):
+            np.testing.assert_allclose(normed.phase[k].cpu().numpy(), g[f"norm_phase{k}"], atol=1e-6)
+            np.testing.assert_allclose(normed.amplitude[k].cpu().numpy(), g[f"norm_amp{k}"], atol=1e-6)
+        np.testing.assert_allclose(normed.low_level.cpu().numpy(), g["norm_low"], atol=1e-6)
+    items = [("high", out.high_level), ("low", out.low_level)]
+    items += [(f"phase{k}", p) for k, p in enumerate(out.phase)] + [(f"amp{k}", a) for k, a in enumerate(out.amplitude)]
+    for name, t in items:
+        ref = g["out_" + name]
+        got = t[..., ::step, ::step].cpu().numpy()
+        assert got.shape == ref.shape, name
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= 1e-4 * scale, (name, np.abs(got - ref).max(), scale)
+    # the values may also arrive without the concat fast path (plain DecompValues)
+    plain = DecompValues(normed.high_level, [p.contiguous() for p in normed.phase],
+                         [a.contiguous() for a in normed.amplitude], normed.low_level)
+    out2 = net(plain)
+    for a, b in zip(out.phase + out.amplitude, out2.phase + out2.amplitude):
+        assert torch.equal(a, b)
+
+
+def test_phasenet_partial_levels_and_protocol(device):
+    pyr = types.SimpleNamespace(height=6, nbands=4)
+    net = PhaseNet(pyr, device)
+    batch = synth.synthetic_vals(5, 6, 32, 48, 6)
+    vin = layout_cpu.get_concat_layers_inf(layout_cpu.separate_vals(batch, 2))
+    dv = DecompValues(vin.high_level.to(device), [p.to(device) for p in vin.phase],
+                      [a.to(device) for a in vin.amplitude], vin.low_level.to(device))
+    with pytest.raises(RuntimeError):
+        net(dv)                               # normalize_vals must come first
+    out = net(net.normalize_vals(dv), m=2)    # hierarchical `m` of phase_net.py:107-110,91-93
+    assert out.phase[0] == 0 and out.phase[1] == 0 and torch.is_tensor(out.phase[2])
