@@ -1,0 +1,585 @@
+// Complex steerable pyramid (frequency domain, scale_factor-generalised) for gfx950:
+// the arithmetic behind Pyramid.filter / inv_filter (reference call sites src/train/pyramid.py:35-46;
+// adapters coeff_to_values / values_to_coeff src/train/pyramid.py:48-112 are fused in).
+//
+// The reference delegates this arithmetic to the third-party `steerable.SCFpyr_PyTorch` (absent, fork
+// unknown: see DESIGN.md, "pyramid spec"); the spec implemented here is the one restated in
+// oracle/pyramid_cpu.py: level k works on the centred ceil(H/s^k) x ceil(W/s^k) window of the
+// spectrum, radial raised-cosine transition shifted by log2(s) per level, nbands oriented analytic bands.
+//
+// Roofline: HBM.  FFTs are plain library transforms (hipFFT, plans cached in the plan object); everything
+// around them is fused into three kernels per level so that no intermediate of the reference's
+// op-by-op chain (mask products, crops, shifts, deepcopy, 2*L*N*4 atan2/abs launches) is materialised:
+//   analysis  : level kernel  : reads the running low-pass spectrum ONCE, writes the nbands band spectra
+//                               (mask * i rotation applied, ifftshift by index arithmetic) and the cropped,
+//                               low-pass filtered spectrum of the next level; level 0 also expands the R2C
+//                               half spectrum and emits the high-pass half spectrum for a C2R transform;
+//               polar kernel  : complex band -> (phase, amplitude) written straight into the caller's
+//                               layout (per-image planes or PhaseNet's concat buffers), optional phase scale;
+//   synthesis : to-complex kernel (A cos p, A sin p), forward FFT, combine kernel (sum of rotated, masked
+//               band spectra + embedded low-pass of the coarser level).
+// All mask tables are precomputed once per plan in double precision, stored in the unshifted (FFT-native)
+// index order so every table read is coalesced with the spectrum access; a thread owns one frequency bin
+// and loops over the N images, so tables are read once per level, not once per image.
+#include "vfi_common.h"
+
+#include <hipfft/hipfft.h>
+
+#include <cmath>
+#include <map>
+#include <new>
+#include <vector>
+
+namespace {
+
+using vfi::ceil_div;
+constexpr int kMaxLevels = 40;
+constexpr int kMaxImages = 16;
+constexpr double kPi = 3.14159265358979323846;
+
+struct Level {
+    int h, w;          // window size
+    float *P_a;        // [nb][h][w] analysis  : angle mask (one sided) * himask, unshifted order
+    float *P_s;        // [nb][h][w] synthesis : angle mask (two sided) * himask
+    float *lomask;     // [h2][w2]  low-pass applied to the NEXT level's window, unshifted order of that window
+};
+
+}  // namespace
+
+struct vfi_pyr_plan {
+    int H, W, height, nbands, nlev, max_images;
+    double scale;
+    std::vector<Level> lev;      // nlev band levels
+    int hl, wl;                  // low residual size
+    float *lo0 = nullptr, *hi0 = nullptr;   // [H][W] unshifted
+    // workspace (complex64 unless noted)
+    float2 *half0 = nullptr;     // N x H x (W/2+1)   R2C spectrum of the input / FFT of high on synthesis
+    float2 *half_hi = nullptr;   // N x H x (W/2+1)   high-pass half spectrum (C2R input)
+    float2 *bands = nullptr;     // N x nb x H x W    band spectra / coefficients of the current level
+    float2 *lod[2] = {nullptr, nullptr};   // N x H x W each: running low-pass spectrum (ping-pong)
+    std::map<std::pair<int, int>, hipfftHandle> c2c;  // (level or -1 = low, -2 = full; batch)
+    std::map<int, hipfftHandle> r2c, c2r;
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+// ---- host-side mask construction (double precision, numpy semantics) -----------------------------------
+double interp(double x, const std::vector<double> &xp, const std::vector<double> &fp) {
+    const size_t n = xp.size();
+    if (x <= xp[0]) return fp[0];
+    if (x >= xp[n - 1]) return fp[n - 1];
+    size_t lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) / 2;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
+    return slope * (x - xp[lo]) + fp[lo];
+}
+
+std::vector<double> linspace_grid(int m) {  // prepare_grid axis
+    std::vector<double> v(m);
+    const double start = -(double)(m / 2) / (m / 2.0);
+    const double stop = (double)(m / 2) / (m / 2.0) - (1 - m % 2) * 2.0 / m;
+    const double step = m > 1 ? (stop - start) / (m - 1) : 0.0;
+    for (int i = 0; i < m; ++i) v[i] = start + i * step;
+    if (m > 1) v[m - 1] = stop;
+    return v;
+}
+
+inline int level_size(int d, double s, int k) { return (int)std::ceil(d / std::pow(s, k) - 1e-9); }
+
+template <typename T>
+int dev_upload(vfi_pyr_plan *p, const std::vector<T> &host, T **dev) {
+    if (hipMalloc((void **)dev, host.size() * sizeof(T)) != hipSuccess) return VFI_ERR_NOMEM;
+    p->allocs.push_back(*dev);
+    if (hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return VFI_ERR_LAUNCH;
+    return VFI_OK;
+}
+
+int dev_alloc(vfi_pyr_plan *p, void **dev, size_t bytes) {
+    if (hipMalloc(dev, bytes) != hipSuccess) return VFI_ERR_NOMEM;
+    p->allocs.push_back(*dev);
+    return VFI_OK;
+}
+
+// shifted-window index (DC at h/2) for an unshifted index u of a length-h axis
+inline int shifted_of(int u, int h) { return (u + h / 2) % h; }
+
+int build_tables(vfi_pyr_plan *p) {
+    const int H = p->H, W = p->W, nb = p->nbands;
+    const std::vector<double> gy = linspace_grid(H), gx = linspace_grid(W);
+    // log_rad / angle on the full shifted grid
+    std::vector<double> log_rad((size_t)H * W), angle((size_t)H * W);
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            angle[(size_t)i * W + j] = std::atan2(gy[i], gx[j]);
+            log_rad[(size_t)i * W + j] = std::sqrt(gx[j] * gx[j] + gy[i] * gy[i]);
+        }
+    if (W > 1) log_rad[(size_t)(H / 2) * W + W / 2] = log_rad[(size_t)(H / 2) * W + W / 2 - 1];
+    for (auto &v : log_rad) v = std::log2(v);
+    // rcosFn(1, -0.5)
+    const int n = 256;
+    std::vector<double> xr(n + 3), yr(n + 3), yir(n + 3);
+    for (int i = 0; i < n + 3; ++i) {
+        const double x = kPi * (double)(i - n - 1) / 2.0 / n;
+        xr[i] = x;
+        yr[i] = std::cos(x) * std::cos(x);
+    }
+    yr[0] = yr[1];
+    yr[n + 2] = yr[n + 1];
+    for (int i = 0; i < n + 3; ++i) {
+        xr[i] = -0.5 + 2.0 / kPi * (xr[i] + kPi / 4.0);
+        yr[i] = std::sqrt(yr[i]);
+        yir[i] = std::sqrt(std::fabs(1.0 - yr[i] * yr[i]));
+    }
+    // angular LUTs
+    const int lut = 1024, order = nb - 1;
+    const int nl = 3 * lut + 3;
+    std::vector<double> xc(nl), ya(nl), ys(nl);
+    double fact_o = 1, fact_2o = 1;
+    for (int i = 2; i <= order; ++i) fact_o *= i;
+    for (int i = 2; i <= 2 * order; ++i) fact_2o *= i;
+    const double cst = std::pow(2.0, 2 * order) * fact_o * fact_o / (nb * fact_2o);
+    for (int i = 0; i < nl; ++i) {
+        xc[i] = kPi * (double)(i - (2 * lut + 1)) / lut;
+        double alpha = std::fmod(xc[i] + kPi, 2 * kPi);
+        if (alpha < 0) alpha += 2 * kPi;
+        alpha -= kPi;
+        const double c = std::pow(std::cos(xc[i]), order);
+        ya[i] = 2.0 * std::sqrt(cst) * c * (std::fabs(alpha) < kPi / 2 ? 1.0 : 0.0);
+        ys[i] = std::sqrt(cst) * c;
+    }
+    std::vector<double> xcb(nl);
+
+    std::vector<float> t((size_t)H * W), t2((size_t)H * W);
+    for (int u = 0; u < H; ++u)
+        for (int v = 0; v < W; ++v) {
+            const size_t s = (size_t)shifted_of(u, H) * W + shifted_of(v, W);
+            t[(size_t)u * W + v] = (float)interp(log_rad[s], xr, yir);
+            t2[(size_t)u * W + v] = (float)interp(log_rad[s], xr, yr);
+        }
+    int rc;
+    if ((rc = dev_upload(p, t, &p->lo0)) || (rc = dev_upload(p, t2, &p->hi0))) return rc;
+
+    for (int k = 0; k < p->nlev; ++k) {
+        Level &L = p->lev[k];
+        for (auto &x : xr) x -= std::log2(p->scale);
+        const int h = L.h, w = L.w, sy = H / 2 - h / 2, sx = W / 2 - w / 2;
+        std::vector<float> pa((size_t)nb * h * w), ps((size_t)nb * h * w);
+        std::vector<float> hm((size_t)h * w);
+        for (int u = 0; u < h; ++u)
+            for (int v = 0; v < w; ++v) {
+                const size_t s = (size_t)(sy + shifted_of(u, h)) * W + (sx + shifted_of(v, w));
+                hm[(size_t)u * w + v] = (float)interp(log_rad[s], xr, yr);
+            }
+        for (int b = 0; b < nb; ++b) {
+            for (int i = 0; i < nl; ++i) xcb[i] = xc[i] + kPi * b / nb;
+            for (int u = 0; u < h; ++u)
+                for (int v = 0; v < w; ++v) {
+                    const size_t s = (size_t)(sy + shifted_of(u, h)) * W + (sx + shifted_of(v, w));
+                    const size_t o = ((size_t)b * h + u) * w + v;
+                    // float32 tables of the oracle multiplied in fp32 there; here folded in double
+                    pa[o] = (float)((double)(float)interp(angle[s], xcb, ya) * (double)hm[(size_t)u * w + v]);
+                    ps[o] = (float)((double)(float)interp(angle[s], xcb, ys) * (double)hm[(size_t)u * w + v]);
+                }
+        }
+        const int h2 = k + 1 < p->nlev ? p->lev[k + 1].h : p->hl, w2 = k + 1 < p->nlev ? p->lev[k + 1].w : p->wl;
+        const int sy2 = H / 2 - h2 / 2, sx2 = W / 2 - w2 / 2;
+        std::vector<float> lm((size_t)h2 * w2);
+        for (int u = 0; u < h2; ++u)
+            for (int v = 0; v < w2; ++v) {
+                const size_t s = (size_t)(sy2 + shifted_of(u, h2)) * W + (sx2 + shifted_of(v, w2));
+                lm[(size_t)u * w2 + v] = (float)interp(log_rad[s], xr, yir);
+            }
+        if ((rc = dev_upload(p, pa, &L.P_a)) || (rc = dev_upload(p, ps, &L.P_s)) || (rc = dev_upload(p, lm, &L.lomask)))
+            return rc;
+    }
+    return VFI_OK;
+}
+
+// ---- device kernels ------------------------------------------------------------------------------------
+struct PlaneMap {          // where image d's band-0 plane goes, in planes of h*w elements from the level base
+    int idx[kMaxImages];
+    int band_stride;       // planes between consecutive bands of one image
+    int complex_coeff;     // 1: `phase` holds interleaved (re, im) coefficients, `amp` is unused
+};
+
+__device__ __forceinline__ int signed_freq(int u, int h) { return u <= h - h / 2 - 1 ? u : u - h; }
+
+// One thread per frequency bin (u, v) of level k's window (unshifted order), looping over the images.
+//   src  : FIRST ? R2C half spectrum N x H x (W/2+1)  :  running low-pass spectrum N x h x w
+//   band : N x NB x h x w  = i * src * P_a[b]                     (build: `lodft * anglemask * himask`, * (-i)^(nb-1))
+//   next : N x h2 x w2     = src * lomask   on the next window     (build: crop, `lomask * lodft`)
+//   FIRST: src = expand(half) * lo0 ; hi_half = half * hi0 / (H*W) for v <= W/2 (C2R input)
+template <bool FIRST, int NB>
+__global__ __launch_bounds__(256) void pyr_analysis_level_kernel(
+    const float2 *__restrict__ src, float2 *__restrict__ band, float2 *__restrict__ next,
+    float2 *__restrict__ hi_half, const float *__restrict__ P_a, const float *__restrict__ lomask,
+    const float *__restrict__ lo0, const float *__restrict__ hi0, int N, int h, int w, int h2, int w2,
+    int write_bands, float inv_hw) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.y;
+    if (v >= w) return;
+    const size_t hw = (size_t)h * w, o = (size_t)u * w + v;
+    float pa[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pa[b] = write_bands ? P_a[(size_t)b * hw + o] : 0.0f;
+    const int fy = signed_freq(u, h), fx = signed_freq(v, w);
+    const bool inside = fy >= -(h2 / 2) && fy <= h2 - h2 / 2 - 1 && fx >= -(w2 / 2) && fx <= w2 - w2 / 2 - 1;
+    const int u2 = fy < 0 ? fy + h2 : fy, v2 = fx < 0 ? fx + w2 : fx;
+    const float lom = inside ? lomask[(size_t)u2 * w2 + v2] : 0.0f;
+    float l0 = 0.0f, h0 = 0.0f;
+    const int wh = w / 2 + 1;
+    if (FIRST) { l0 = lo0[o]; h0 = hi0[o]; }
+    for (int n = 0; n < N; ++n) {
+        float2 z;
+        if (FIRST) {
+            if (v < wh) {
+                z = src[((size_t)n * h + u) * wh + v];
+                hi_half[((size_t)n * h + u) * wh + v] = make_float2(z.x * h0 * inv_hw, z.y * h0 * inv_hw);
+            } else {
+                const float2 c = src[((size_t)n * h + (u ? h - u : 0)) * wh + (w - v)];
+                z = make_float2(c.x, -c.y);
+            }
+            z = make_float2(z.x * l0, z.y * l0);
+        } else {
+            z = src[(size_t)n * hw + o];
+        }
+        if (write_bands) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)  // * i : (re, im) -> (-im, re)
+                band[((size_t)n * NB + b) * hw + o] = make_float2(-(z.y * pa[b]), z.x * pa[b]);
+        }
+        if (inside) next[((size_t)n * h2 + u2) * w2 + v2] = make_float2(z.x * lom, z.y * lom);
+    }
+}
+
+// complex band coefficient (after the un-normalised inverse FFT) -> phase, amplitude in the caller's layout
+// (coeff_to_values: src/train/pyramid.py:63-69)
+template <int NB>
+__global__ __launch_bounds__(256) void pyr_polar_kernel(const float2 *__restrict__ band, float *__restrict__ phase,
+                                                        float *__restrict__ amp, PlaneMap pm, int N, int hw,
+                                                        float inv_hw, float phase_scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb_idx = blockIdx.y;  // n * NB + b
+    if (i >= hw) return;
+    const int n = nb_idx / NB, b = nb_idx % NB;
+    const float2 z = band[(size_t)nb_idx * hw + i];
+    const float re = z.x * inv_hw, im = z.y * inv_hw;
+    const size_t o = (size_t)(pm.idx[n] + b * pm.band_stride) * hw + i;
+    if (pm.complex_coeff) {
+        reinterpret_cast<float2 *>(phase)[o] = make_float2(re, im);
+    } else {
+        phase[o] = atan2f(im, re) * phase_scale;
+        amp[o] = sqrtf(re * re + im * im);
+    }
+}
+
+// (phase, amplitude) -> complex coefficient (values_to_coeff: src/train/pyramid.py:99-107)
+template <int NB>
+__global__ __launch_bounds__(256) void pyr_to_complex_kernel(const float *__restrict__ phase, const float *__restrict__ amp,
+                                                             float2 *__restrict__ band, PlaneMap pm, int N, int hw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb_idx = blockIdx.y;
+    if (i >= hw) return;
+    const int n = nb_idx / NB, b = nb_idx % NB;
+    const size_t o = (size_t)(pm.idx[n] + b * pm.band_stride) * hw + i;
+    if (pm.complex_coeff) {
+        band[(size_t)nb_idx * hw + i] = reinterpret_cast<const float2 *>(phase)[o];
+    } else {
+        float s, c;
+        sincosf(phase[o], &s, &c);
+        const float a = amp[o];
+        band[(size_t)nb_idx * hw + i] = make_float2(c * a, s * a);
+    }
+}
+
+// cur = sum_b (-i) * FFT(band_b) * P_s[b]  +  embed(res * lomask)     (reconstruct: orientdft + resdft)
+template <int NB>
+__global__ __launch_bounds__(256) void pyr_combine_kernel(const float2 *__restrict__ band, const float2 *__restrict__ res,
+                                                          float2 *__restrict__ cur, const float *__restrict__ P_s,
+                                                          const float *__restrict__ lomask, int N, int h, int w,
+                                                          int h2, int w2, int have_bands) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.y;
+    if (v >= w) return;
+    const size_t hw = (size_t)h * w, o = (size_t)u * w + v;
+    float ps[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ps[b] = have_bands ? P_s[(size_t)b * hw + o] : 0.0f;
+    const int fy = signed_freq(u, h), fx = signed_freq(v, w);
+    const bool inside = fy >= -(h2 / 2) && fy <= h2 - h2 / 2 - 1 && fx >= -(w2 / 2) && fx <= w2 - w2 / 2 - 1;
+    const int u2 = fy < 0 ? fy + h2 : fy, v2 = fx < 0 ? fx + w2 : fx;
+    const float lom = inside ? lomask[(size_t)u2 * w2 + v2] : 0.0f;
+    for (int n = 0; n < N; ++n) {
+        float2 acc = make_float2(0.0f, 0.0f);
+        if (have_bands) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {  // * (-i) : (re, im) -> (im, -re)
+                const float2 z = band[((size_t)n * NB + b) * hw + o];
+                acc.x += z.y * ps[b];
+                acc.y -= z.x * ps[b];
+            }
+        }
+        if (inside) {
+            const float2 r = res[((size_t)n * h2 + u2) * w2 + v2];
+            acc.x += r.x * lom;
+            acc.y += r.y * lom;
+        }
+        cur[(size_t)n * hw + o] = acc;
+    }
+}
+
+// real image -> complex (imag 0) ; complex -> real * scale
+__global__ void real_to_complex_kernel(const float *__restrict__ x, float2 *__restrict__ z, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        z[i] = make_float2(x ? x[i] : 0.0f, 0.0f);
+}
+__global__ void complex_real_kernel(const float2 *__restrict__ z, float *__restrict__ x, long long total, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        x[i] = z[i].x * scale;
+}
+// out = cur * lo0 + expand(hi_half) * hi0     (reconstruct: `tempdft * lo0mask + hidft * hi0mask`)
+__global__ __launch_bounds__(256) void pyr_final_kernel(float2 *__restrict__ cur, const float2 *__restrict__ hi_half,
+                                                        const float *__restrict__ lo0, const float *__restrict__ hi0,
+                                                        int N, int h, int w) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.y;
+    if (v >= w) return;
+    const size_t hw = (size_t)h * w, o = (size_t)u * w + v;
+    const float l0 = lo0[o], h0 = hi0[o];
+    const int wh = w / 2 + 1;
+    for (int n = 0; n < N; ++n) {
+        float2 z = cur[(size_t)n * hw + o];
+        z.x *= l0; z.y *= l0;
+        if (hi_half) {
+            float2 c;
+            if (v < wh) c = hi_half[((size_t)n * h + u) * wh + v];
+            else { c = hi_half[((size_t)n * h + (u ? h - u : 0)) * wh + (w - v)]; c.y = -c.y; }
+            z.x += c.x * h0; z.y += c.y * h0;
+        }
+        cur[(size_t)n * hw + o] = z;
+    }
+}
+
+// ---- FFT plan cache ---------------------------------------------------------------------------------------
+int get_c2c(vfi_pyr_plan *p, int key, int h, int w, int batch, hipfftHandle *out) {
+    auto it = p->c2c.find({key, batch});
+    if (it != p->c2c.end()) { *out = it->second; return VFI_OK; }
+    hipfftHandle hnd;
+    int n[2] = {h, w};
+    hipfftResult r = hipfftPlanMany(&hnd, 2, n, nullptr, 1, h * w, nullptr, 1, h * w, HIPFFT_C2C, batch);
+    if (r != HIPFFT_SUCCESS) return vfi::fail(VFI_ERR_FFT, "hipfftPlanMany C2C %dx%d batch %d: %d", h, w, batch, (int)r);
+    p->c2c[{key, batch}] = hnd;
+    *out = hnd;
+    return VFI_OK;
+}
+int get_real(vfi_pyr_plan *p, bool forward, int batch, hipfftHandle *out) {
+    auto &m = forward ? p->r2c : p->c2r;
+    auto it = m.find(batch);
+    if (it != m.end()) { *out = it->second; return VFI_OK; }
+    hipfftHandle hnd;
+    int n[2] = {p->H, p->W};
+    const int wh = p->W / 2 + 1;
+    hipfftResult r = forward
+        ? hipfftPlanMany(&hnd, 2, n, nullptr, 1, p->H * p->W, nullptr, 1, p->H * wh, HIPFFT_R2C, batch)
+        : hipfftPlanMany(&hnd, 2, n, nullptr, 1, p->H * wh, nullptr, 1, p->H * p->W, HIPFFT_C2R, batch);
+    if (r != HIPFFT_SUCCESS) return vfi::fail(VFI_ERR_FFT, "hipfftPlanMany %s %dx%d batch %d: %d", forward ? "R2C" : "C2R",
+                                              p->H, p->W, batch, (int)r);
+    m[batch] = hnd;
+    *out = hnd;
+    return VFI_OK;
+}
+#define FFT_CHECK(expr, what)                                                              \
+    do {                                                                                   \
+        hipfftResult r_ = (expr);                                                          \
+        if (r_ != HIPFFT_SUCCESS) return vfi::fail(VFI_ERR_FFT, "%s: hipfft error %d", what, (int)r_); \
+    } while (0)
+
+PlaneMap make_map(const int *plane_index, int level, int N, int nb, int flags) {
+    PlaneMap pm;
+    const bool band_major = flags & VFI_PYR_BAND_MAJOR;
+    for (int d = 0; d < kMaxImages; ++d)
+        pm.idx[d] = d < N ? (plane_index ? plane_index[level * N + d] : (band_major ? d : d * nb)) : 0;
+    pm.band_stride = band_major ? N : 1;
+    pm.complex_coeff = (flags & VFI_PYR_COMPLEX_COEFF) ? 1 : 0;
+    return pm;
+}
+
+inline int blocks_1d(long long n) { long long b = (n + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+extern "C" int vfi_pyr_plan_create(int H, int W, int height, int nbands, double scale_factor, int max_images,
+                                   vfi_pyr_plan **out) {
+    VFI_REQUIRE(out, VFI_ERR_INVALID_ARG, "vfi_pyr_plan_create: null out");
+    *out = nullptr;
+    VFI_REQUIRE(H >= 4 && W >= 4 && height >= 3 && height - 2 <= kMaxLevels, VFI_ERR_INVALID_ARG,
+                "vfi_pyr_plan_create: bad size %dx%d height %d", H, W, height);
+    VFI_REQUIRE(nbands == 4, VFI_ERR_UNSUPPORTED, "vfi_pyr_plan_create: nbands=%d (the path uses 4)", nbands);
+    VFI_REQUIRE(scale_factor > 1.0 && scale_factor <= 2.0, VFI_ERR_INVALID_ARG, "vfi_pyr_plan_create: scale_factor %g", scale_factor);
+    VFI_REQUIRE(max_images >= 1 && max_images <= kMaxImages, VFI_ERR_INVALID_ARG, "vfi_pyr_plan_create: max_images %d", max_images);
+    vfi_pyr_plan *p = new (std::nothrow) vfi_pyr_plan();
+    VFI_REQUIRE(p, VFI_ERR_NOMEM, "vfi_pyr_plan_create: host allocation");
+    p->H = H; p->W = W; p->height = height; p->nbands = nbands; p->nlev = height - 2; p->scale = scale_factor;
+    p->max_images = max_images;
+    p->lev.resize(p->nlev);
+    for (int k = 0; k < p->nlev; ++k) { p->lev[k].h = level_size(H, scale_factor, k); p->lev[k].w = level_size(W, scale_factor, k); }
+    p->hl = level_size(H, scale_factor, p->nlev);
+    p->wl = level_size(W, scale_factor, p->nlev);
+    int rc = VFI_OK;
+    if (p->hl < 2 || p->wl < 2) rc = vfi::fail(VFI_ERR_SHAPE, "vfi_pyr_plan_create: height %d too large for %dx%d", height, H, W);
+    if (!rc) rc = build_tables(p);
+    const size_t N = max_images, HW = (size_t)H * W, half = (size_t)H * (W / 2 + 1);
+    if (!rc) rc = dev_alloc(p, (void **)&p->half0, N * half * sizeof(float2));
+    if (!rc) rc = dev_alloc(p, (void **)&p->half_hi, N * half * sizeof(float2));
+    if (!rc) rc = dev_alloc(p, (void **)&p->bands, N * nbands * HW * sizeof(float2));
+    if (!rc) rc = dev_alloc(p, (void **)&p->lod[0], N * HW * sizeof(float2));
+    if (!rc) rc = dev_alloc(p, (void **)&p->lod[1], N * HW * sizeof(float2));
+    if (rc) {
+        if (rc == VFI_ERR_NOMEM) vfi::set_error("vfi_pyr_plan_create: device allocation failed");
+        vfi_pyr_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return VFI_OK;
+}
+
+extern "C" int vfi_pyr_plan_destroy(vfi_pyr_plan *p) {
+    if (!p) return VFI_OK;
+    for (auto &kv : p->c2c) hipfftDestroy(kv.second);
+    for (auto &kv : p->r2c) hipfftDestroy(kv.second);
+    for (auto &kv : p->c2r) hipfftDestroy(kv.second);
+    for (void *d : p->allocs) (void)hipFree(d);
+    delete p;
+    return VFI_OK;
+}
+
+extern "C" int vfi_pyr_plan_level_size(const vfi_pyr_plan *p, int level, int *h, int *w) {
+    VFI_REQUIRE(p && h && w, VFI_ERR_INVALID_ARG, "vfi_pyr_plan_level_size: null pointer");
+    VFI_REQUIRE(level >= 0 && level <= p->nlev, VFI_ERR_INVALID_ARG, "vfi_pyr_plan_level_size: level %d", level);
+    *h = level < p->nlev ? p->lev[level].h : p->hl;
+    *w = level < p->nlev ? p->lev[level].w : p->wl;
+    return VFI_OK;
+}
+
+extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *high, float *const *phase,
+                               float *const *amp, const int *plane_index, float *low, float phase_scale,
+                               unsigned long long level_mask, int flags, vfi_stream_t stream) {
+    VFI_REQUIRE(p && img, VFI_ERR_INVALID_ARG, "vfi_pyr_analyze: null pointer");
+    VFI_REQUIRE(N >= 1 && N <= p->max_images, VFI_ERR_INVALID_ARG, "vfi_pyr_analyze: N=%d (plan max %d)", N, p->max_images);
+    VFI_REQUIRE((phase && (amp || (flags & VFI_PYR_COMPLEX_COEFF))) || level_mask == 0, VFI_ERR_INVALID_ARG,
+                "vfi_pyr_analyze: null phase/amp tables");
+    hipStream_t s = vfi::as_stream(stream);
+    const int H = p->H, W = p->W, nb = p->nbands;
+    hipfftHandle f;
+    int rc;
+    if ((rc = get_real(p, true, N, &f))) return rc;
+    FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_analyze");
+    FFT_CHECK(hipfftExecR2C(f, const_cast<float *>(img), reinterpret_cast<hipfftComplex *>(p->half0)), "vfi_pyr_analyze R2C");
+    const float2 *src = p->half0;
+    for (int k = 0; k < p->nlev; ++k) {
+        const Level &L = p->lev[k];
+        const int h2 = k + 1 < p->nlev ? p->lev[k + 1].h : p->hl, w2 = k + 1 < p->nlev ? p->lev[k + 1].w : p->wl;
+        float2 *next = p->lod[k & 1];
+        const int wb = (level_mask >> k) & 1ull ? 1 : 0;
+        if (wb) VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
+                            "vfi_pyr_analyze: null output for level %d", k);
+        dim3 grid(ceil_div(L.w, 256), L.h);
+        if (k == 0)
+            hipLaunchKernelGGL((pyr_analysis_level_kernel<true, 4>), grid, dim3(256), 0, s, src, p->bands, next, p->half_hi,
+                               L.P_a, L.lomask, p->lo0, p->hi0, N, L.h, L.w, h2, w2, wb, 1.0f / ((float)H * (float)W));
+        else
+            hipLaunchKernelGGL((pyr_analysis_level_kernel<false, 4>), grid, dim3(256), 0, s, src, p->bands, next, nullptr,
+                               L.P_a, L.lomask, nullptr, nullptr, N, L.h, L.w, h2, w2, wb, 0.0f);
+        if (wb) {
+            if ((rc = get_c2c(p, k, L.h, L.w, N * nb, &f))) return rc;
+            FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_analyze");
+            FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(p->bands), reinterpret_cast<hipfftComplex *>(p->bands),
+                                    HIPFFT_BACKWARD), "vfi_pyr_analyze band IFFT");
+            const int hw = L.h * L.w;
+            hipLaunchKernelGGL((pyr_polar_kernel<4>), dim3(ceil_div(hw, 256), N * nb), dim3(256), 0, s, p->bands, phase[k],
+                               amp ? amp[k] : nullptr, make_map(plane_index, k, N, nb, flags), N, hw, 1.0f / (float)hw,
+                               phase_scale);
+        }
+        src = next;
+    }
+    if (low) {  // low residual: real(ifft2(lodft))
+        if ((rc = get_c2c(p, -1, p->hl, p->wl, N, &f))) return rc;
+        FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_analyze");
+        float2 *buf = const_cast<float2 *>(src);
+        FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(buf), reinterpret_cast<hipfftComplex *>(buf), HIPFFT_BACKWARD),
+                  "vfi_pyr_analyze low IFFT");
+        const long long tot = (long long)N * p->hl * p->wl;
+        hipLaunchKernelGGL(complex_real_kernel, dim3(blocks_1d(tot)), dim3(256), 0, s, buf, low, tot,
+                           1.0f / ((float)p->hl * (float)p->wl));
+    }
+    if (high) {  // high residual: C2R of half * hi0 / (H W)
+        if ((rc = get_real(p, false, N, &f))) return rc;
+        FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_analyze");
+        FFT_CHECK(hipfftExecC2R(f, reinterpret_cast<hipfftComplex *>(p->half_hi), high), "vfi_pyr_analyze C2R");
+    }
+    return vfi::check_launch("vfi_pyr_analyze");
+}
+
+extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const float *const *phase, const float *const *amp,
+                                  const int *plane_index, const float *low, unsigned long long level_mask, int flags,
+                                  float *img, int N, vfi_stream_t stream) {
+    VFI_REQUIRE(p && img, VFI_ERR_INVALID_ARG, "vfi_pyr_synthesize: null pointer");
+    VFI_REQUIRE(N >= 1 && N <= p->max_images, VFI_ERR_INVALID_ARG, "vfi_pyr_synthesize: N=%d (plan max %d)", N, p->max_images);
+    VFI_REQUIRE((phase && (amp || (flags & VFI_PYR_COMPLEX_COEFF))) || level_mask == 0, VFI_ERR_INVALID_ARG,
+                "vfi_pyr_synthesize: null phase/amp tables");
+    hipStream_t s = vfi::as_stream(stream);
+    const int H = p->H, W = p->W, nb = p->nbands;
+    hipfftHandle f;
+    int rc;
+    // coarsest: res = FFT(low) (zeros when low is NULL)
+    float2 *res = p->lod[p->nlev & 1];
+    {
+        const long long tot = (long long)N * p->hl * p->wl;
+        hipLaunchKernelGGL(real_to_complex_kernel, dim3(blocks_1d(tot)), dim3(256), 0, s, low, res, tot);
+        if (low) {
+            if ((rc = get_c2c(p, -1, p->hl, p->wl, N, &f))) return rc;
+            FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_synthesize");
+            FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(res), reinterpret_cast<hipfftComplex *>(res), HIPFFT_FORWARD),
+                      "vfi_pyr_synthesize low FFT");
+        }
+    }
+    for (int k = p->nlev - 1; k >= 0; --k) {
+        const Level &L = p->lev[k];
+        const int h2 = k + 1 < p->nlev ? p->lev[k + 1].h : p->hl, w2 = k + 1 < p->nlev ? p->lev[k + 1].w : p->wl;
+        const int hb = (level_mask >> k) & 1ull ? 1 : 0;
+        const int hw = L.h * L.w;
+        if (hb) {
+            VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
+                        "vfi_pyr_synthesize: null input for level %d", k);
+            hipLaunchKernelGGL((pyr_to_complex_kernel<4>), dim3(ceil_div(hw, 256), N * nb), dim3(256), 0, s, phase[k],
+                               amp ? amp[k] : nullptr, p->bands, make_map(plane_index, k, N, nb, flags), N, hw);
+            if ((rc = get_c2c(p, k, L.h, L.w, N * nb, &f))) return rc;
+            FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_synthesize");
+            FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(p->bands), reinterpret_cast<hipfftComplex *>(p->bands),
+                                    HIPFFT_FORWARD), "vfi_pyr_synthesize band FFT");
+        }
+        float2 *cur = p->lod[k & 1];
+        hipLaunchKernelGGL((pyr_combine_kernel<4>), dim3(ceil_div(L.w, 256), L.h), dim3(256), 0, s, p->bands, res, cur, L.P_s,
+                           L.lomask, N, L.h, L.w, h2, w2, hb);
+        res = cur;
+    }
+    const float2 *hi_half = nullptr;
+    if (high) {
+        if ((rc = get_real(p, true, N, &f))) return rc;
+        FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_synthesize");
+        FFT_CHECK(hipfftExecR2C(f, const_cast<float *>(high), reinterpret_cast<hipfftComplex *>(p->half0)), "vfi_pyr_synthesize R2C");
+        hi_half = p->half0;
+    }
+    hipLaunchKernelGGL(pyr_final_kernel, dim3(ceil_div(W, 256), H), dim3(256), 0, s, res, hi_half, p->lo0, p->hi0, N, H, W);
+    if ((rc = get_c2c(p, -2, H, W, N, &f))) return rc;
+    FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_synthesize");
+    FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(res), reinterpret_cast<hipfftComplex *>(res), HIPFFT_BACKWARD),
+              "vfi_pyr_synthesize final IFFT");
+    const long long tot = (long long)N * H * W;
+    hipLaunchKernelGGL(complex_real_kernel, dim3(blocks_1d(tot)), dim3(256), 0, s, res, img, tot, 1.0f / ((float)H * (float)W));
+    return vfi::check_launch("vfi_pyr_synthesize");
+}

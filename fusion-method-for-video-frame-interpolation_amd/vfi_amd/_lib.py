@@ -34,6 +34,13 @@ SIGNATURES = {
     "vfi_phasenet_emit": [c_f, c_l, c_f, c_l, c_f, c_f, c_f, c_i, c_i, c_s],
     "vfi_phasenet_emit_low": [c_f, c_l, c_f, c_l, c_f, c_f, c_i, c_i, c_s],
     "vfi_tanh_residual_clamp": [c_f, c_f, c_f, c_l, c_s],
+    "vfi_pyr_plan_create": [c_i, c_i, c_i, c_i, c_d, c_i, ctypes.POINTER(ctypes.c_void_p)],
+    "vfi_pyr_plan_destroy": [ctypes.c_void_p],
+    "vfi_pyr_plan_level_size": [ctypes.c_void_p, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
+    "vfi_pyr_analyze": [ctypes.c_void_p, c_f, c_i, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f,
+                        c_fl, ctypes.c_ulonglong, c_i, c_s],
+    "vfi_pyr_synthesize": [ctypes.c_void_p, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f,
+                           ctypes.c_ulonglong, c_i, c_f, c_i, c_s],
 }
 # entry points that return a value instead of a vfi_status
 RESTYPES = {"vfi_conv2d_packed_floats": c_l}

@@ -169,6 +169,54 @@ int vfi_phasenet_emit_low(const float *pred, long long pred_bstride, const float
 /* FusionNet tail (fusion_net.py:70-77): y = clamp(base + tanh(x), 0, 1) over `count` floats. */
 int vfi_tanh_residual_clamp(const float *x, const float *base, float *y, long long count, vfi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Complex steerable pyramid (frequency domain), scale_factor-generalised
+ * ---------------------------------------------------------------------------------- */
+
+/* Opaque plan: level geometry, mask tables, hipFFT plans and workspace for one
+ * (H, W, height, nbands, scale_factor).  Replaces the per-frame construction of
+ * `SCFpyr_PyTorch(height, nbands, scale_factor, device)` (reference src/train/pyramid.py:28-33,
+ * rebuilt for every frame at src/fusion_net/interpolate_twoframe.py:124-129).  Creation allocates
+ * device memory and synchronises; everything else only enqueues.  A plan is used from one host
+ * thread at a time (hipFFT plans carry their stream). */
+typedef struct vfi_pyr_plan vfi_pyr_plan;
+
+enum {
+    VFI_PYR_BAND_MAJOR = 1,    /* default plane of image d, band b is d*nbands+b; with this flag b*N+d */
+    VFI_PYR_COMPLEX_COEFF = 2  /* bands are interleaved (re, im) coefficients instead of (phase, amplitude) */
+};
+
+int vfi_pyr_plan_create(int H, int W, int height, int nbands, double scale_factor, int max_images,
+                        vfi_pyr_plan **out);
+int vfi_pyr_plan_destroy(vfi_pyr_plan *plan);
+/* Size of band level `level` (0 = finest .. height-3) or of the low residual (level == height-2):
+ * ceil(H / scale_factor^level) x ceil(W / scale_factor^level). */
+int vfi_pyr_plan_level_size(const vfi_pyr_plan *plan, int level, int *h, int *w);
+
+/* Pyramid.filter = SCFpyr_PyTorch.build + coeff_to_values (src/train/pyramid.py:35-39,48-78).
+ *   img    (N, H, W)
+ *   high   (N, H, W) or NULL;  low (N, hL, wL) or NULL
+ *   phase[k], amp[k] (k < height-2; host arrays of device pointers): band level k, finest first.
+ *          The plane (h_k*w_k floats) of image d, band b starts at plane index
+ *          plane_index[k*N + d] + b*band_stride from phase[k] / amp[k]; plane_index == NULL gives the
+ *          reference's per-image layout (N*nbands, 1, h, w) with index d*nbands+b.  A custom table lets
+ *          the bands land directly in PhaseNet's (colour, frame*nbands+band) block-input buffers
+ *          (separate_vals + get_concat_layers_inf, src/train/utils.py:47-127, without the copies).
+ *   phase_scale multiplies the phase (1, or 1/pi for PhaseNet.normalize_vals, src/phase_net/phase_net.py:64)
+ *   level_mask  bit k set = produce band level k (clear bits skip that level's inverse FFTs)
+ *   flags       VFI_PYR_* */
+int vfi_pyr_analyze(vfi_pyr_plan *plan, const float *img, int N, float *high, float *const *phase,
+                    float *const *amp, const int *plane_index, float *low, float phase_scale,
+                    unsigned long long level_mask, int flags, vfi_stream_t stream);
+
+/* Pyramid.inv_filter = values_to_coeff + SCFpyr_PyTorch.reconstruct (src/train/pyramid.py:41-46,85-112).
+ * high / low may be NULL (treated as zeros, e.g. PhaseNet's high_level, src/phase_net/phase_net.py:127-128);
+ * band levels whose level_mask bit is clear are treated as zeros (get_last_value_levels /
+ * get_first_value_levels, src/train/utils.py:242-320, without materialising the zero tensors). */
+int vfi_pyr_synthesize(vfi_pyr_plan *plan, const float *high, const float *const *phase,
+                       const float *const *amp, const int *plane_index, const float *low,
+                       unsigned long long level_mask, int flags, float *img, int N, vfi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

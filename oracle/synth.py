@@ -11,7 +11,7 @@ from .nets_cpu import DecompValues
 
 def level_sizes(h, w, height):
     """Band-level sizes finest-first and the low-residual size: ceil(d / 2^(k/2))."""
-    lv = [(math.ceil(h / 2 ** (k / 2)), math.ceil(w / 2 ** (k / 2))) for k in range(height - 1)]
+    lv = [(math.ceil(h / 2 ** (k / 2) - 1e-9), math.ceil(w / 2 ** (k / 2) - 1e-9)) for k in range(height - 1)]
     return lv[:-1], lv[-1]
 
 

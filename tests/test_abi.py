@@ -13,7 +13,7 @@ from vfi_amd import _lib
 def _declared():
     text = open(os.path.join(ROOT, "include", "vfi_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    text = re.sub(r"typedef enum.*?;", "", text, flags=re.S)
+    text = re.sub(r"(typedef )?enum.*?;", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(vfi_[a-z0-9_]+)\s*\(", text)))
 
 
