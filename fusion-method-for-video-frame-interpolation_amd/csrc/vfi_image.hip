@@ -1,0 +1,237 @@
+// Image-space stages of the fused per-frame path that the reference runs on the HOST CPU
+// (skimage / scipy round trips, reference src/fusion_net/interpolate_twoframe.py:148-149,190-225):
+//   rgb <-> Lab             reference src/train/transform.py:17-25,40-49 (skimage.color, D65 / 2 deg)
+//   Gaussian sigma=5         scipy.ndimage.gaussian_filter(x, 5)         (interpolate_twoframe.py:212-213)
+//   50x50 median             scipy.ndimage.median_filter(x, size=50)     (interpolate_twoframe.py:221-222)
+//   colour mean / |a-b| / scale / clamp glue around them                (interpolate_twoframe.py:207-225)
+// Keeping them on the GPU removes five device<->host round trips per frame; the 50x50 median alone
+// costs the reference 66 s per 1080p frame on 8 CPU cores.
+#include "vfi_common.h"
+
+namespace {
+
+using vfi::ceil_div;
+inline int blocks_1d(long long n) { long long b = (n + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
+
+// ---- colour -------------------------------------------------------------------------------------------
+// skimage.color.rgb2lab: sRGB -> linear -> XYZ (xyz_from_rgb) -> / D65 white -> f(t) -> Lab; then the
+// reference's scaling L/100, (a+128)/255, (b+128)/255 (transform.py:20-22).
+__global__ void rgb2lab_kernel(const float *__restrict__ rgb, float *__restrict__ lab, int N, int HW) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = i % HW, n = i / HW;
+        const float *s = rgb + (size_t)n * 3 * HW + p;
+        float c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = s[(size_t)k * HW];
+            c[k] = v > 0.04045f ? powf((v + 0.055f) / 1.055f, 2.4f) : v / 12.92f;
+        }
+        float x = 0.412453f * c[0] + 0.357580f * c[1] + 0.180423f * c[2];
+        float y = 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2];
+        float z = 0.019334f * c[0] + 0.119193f * c[1] + 0.950227f * c[2];
+        x /= 0.95047f; z /= 1.08883f;
+        auto f = [](float t) { return t > 0.008856f ? cbrtf(t) : 7.787f * t + 16.0f / 116.0f; };
+        const float fx = f(x), fy = f(y), fz = f(z);
+        float *d = lab + (size_t)n * 3 * HW + p;
+        d[0] = (116.0f * fy - 16.0f) / 100.0f;
+        d[(size_t)HW] = (500.0f * (fx - fy) + 128.0f) / 255.0f;
+        d[(size_t)2 * HW] = (200.0f * (fy - fz) + 128.0f) / 255.0f;
+    }
+}
+
+// skimage.color.lab2rgb after the reference's un-scaling (transform.py:43-45): Lab -> XYZ (z < 0 -> 0)
+// -> linear rgb (inverse matrix) -> sRGB gamma -> clip [0,1].
+__global__ void lab2rgb_kernel(const float *__restrict__ lab, float *__restrict__ rgb, int N, int HW) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = i % HW, n = i / HW;
+        const float *s = lab + (size_t)n * 3 * HW + p;
+        const float L = s[0] * 100.0f, a = s[(size_t)HW] * 255.0f - 128.0f, b = s[(size_t)2 * HW] * 255.0f - 128.0f;
+        const float fy = (L + 16.0f) / 116.0f;
+        const float fx = a / 500.0f + fy;
+        float fz = fy - b / 200.0f;
+        fz = fz < 0.0f ? 0.0f : fz;
+        auto g = [](float t) { return t > 0.2068966f ? t * t * t : (t - 16.0f / 116.0f) / 7.787f; };
+        const float x = g(fx) * 0.95047f, y = g(fy), z = g(fz) * 1.08883f;
+        // rgb_from_xyz = inv(xyz_from_rgb)
+        float c[3];
+        c[0] = 3.24048134f * x - 1.53715152f * y - 0.49853633f * z;
+        c[1] = -0.96925495f * x + 1.87599f * y + 0.04155593f * z;
+        c[2] = 0.05564664f * x - 0.20404134f * y + 1.05731107f * z;
+        float *d = rgb + (size_t)n * 3 * HW + p;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = c[k] > 0.0031308f ? 1.055f * powf(c[k], 1.0f / 2.4f) - 0.055f : c[k] * 12.92f;
+            d[(size_t)k * HW] = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+    }
+}
+
+// ---- colour mean / difference glue --------------------------------------------------------------------------
+// out[p] = (mean_c a[c][p] (- mean_c b[c][p], abs)) * scale, optionally clamped to [0,1]
+__global__ void channel_mean_diff_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out,
+                                         int N, int C, int HW, float scale, int clamp01) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = i % HW, n = i / HW;
+        float sa = 0.0f, sb = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            sa += a[((size_t)n * C + c) * HW + p];
+            if (b) sb += b[((size_t)n * C + c) * HW + p];
+        }
+        float v = sa / (float)C;
+        if (b) v = fabsf(v - sb / (float)C);
+        v *= scale;
+        out[i] = clamp01 ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
+    }
+}
+// out = |x - y| * scale, optionally clamped   (subtract_values: src/train/utils.py:322-346; :223-224)
+__global__ void absdiff_kernel(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out,
+                               long long total, float scale, int clamp01) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i] - y[i]) * scale;
+        out[i] = clamp01 ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
+    }
+}
+
+// ---- separable Gaussian, scipy 'reflect' boundary (d c b a | a b c d | d c b a) --------------------------------
+constexpr int kMaxRadius = 64;
+struct GaussTaps { float w[2 * kMaxRadius + 1]; int radius; };
+
+__device__ __forceinline__ int sym_reflect(int i, int n) {  // scipy mode='reflect' (half-sample symmetric)
+    if (n == 1) return 0;
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+template <bool VERTICAL>
+__global__ void gauss_pass_kernel(const float *__restrict__ x, float *__restrict__ y, int N, int H, int W, GaussTaps t) {
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int xx = i % W, yy = (i / W) % H, n = i / ((long long)W * H);
+        const float *p = x + (size_t)n * H * W;
+        float acc = 0.0f;
+        for (int k = -t.radius; k <= t.radius; ++k) {
+            const int sy = VERTICAL ? sym_reflect(yy + k, H) : yy;
+            const int sx = VERTICAL ? xx : sym_reflect(xx + k, W);
+            acc += t.w[k + t.radius] * p[(size_t)sy * W + sx];
+        }
+        y[i] = acc;
+    }
+}
+
+// ---- size x size median, scipy semantics (mode='reflect', origin 0, rank size*size/2) -----------------------------
+// Exact selection.  A 32x8 output tile stages its (32+S-1) x (8+S-1) input window in LDS as order-preserving
+// 32-bit keys; each thread then bisects the key range [min, max] of ITS window for the smallest key whose
+// rank reaches the median: every step is one conflict-free sweep of the window in LDS.
+__device__ __forceinline__ unsigned key_of(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float float_of(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+constexpr int kMedTW = 32, kMedTH = 8;
+
+__global__ __launch_bounds__(256) void median_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, int S) {
+    extern __shared__ unsigned tile[];
+    const int PW = kMedTW + S - 1, PH = kMedTH + S - 1;
+    const int n = blockIdx.z;
+    const int x0 = blockIdx.x * kMedTW, y0 = blockIdx.y * kMedTH;
+    const int lo_off = S / 2;  // window of output i covers [i - S/2, i - S/2 + S - 1]
+    const float *p = x + (size_t)n * H * W;
+    for (int e = threadIdx.x; e < PW * PH; e += 256) {
+        const int r = e / PW, c = e % PW;
+        const int sy = sym_reflect(y0 - lo_off + r, H), sx = sym_reflect(x0 - lo_off + c, W);
+        tile[e] = key_of(p[(size_t)sy * W + sx]);
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % kMedTW, ty = threadIdx.x / kMedTW;
+    const int gx = x0 + tx, gy = y0 + ty;
+    const unsigned *base = tile + ty * PW + tx;
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    for (int r = 0; r < S; ++r)
+        for (int c = 0; c < S; ++c) {
+            const unsigned k = base[r * PW + c];
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+    const int need = (S * S) / 2 + 1;  // smallest key with count(key <= K) >= rank+1
+    unsigned lo = kmin, hi = kmax;
+    while (__any(lo < hi)) {
+        const bool active = lo < hi;
+        const unsigned mid = lo + (hi - lo) / 2;
+        int cnt = 0;
+        for (int r = 0; r < S; ++r)
+            for (int c = 0; c < S; ++c) cnt += base[r * PW + c] <= mid ? 1 : 0;
+        if (active) {
+            if (cnt >= need) hi = mid; else lo = mid + 1;
+        }
+    }
+    if (gx < W && gy < H) y[(size_t)n * H * W + (size_t)gy * W + gx] = float_of(lo);
+}
+
+}  // namespace
+
+extern "C" int vfi_rgb2lab(const float *rgb, float *lab, int N, int HW, vfi_stream_t stream) {
+    VFI_REQUIRE(rgb && lab, VFI_ERR_INVALID_ARG, "vfi_rgb2lab: null pointer");
+    VFI_REQUIRE(N > 0 && HW > 0, VFI_ERR_INVALID_ARG, "vfi_rgb2lab: bad sizes");
+    hipLaunchKernelGGL(rgb2lab_kernel, dim3(blocks_1d((long long)N * HW)), dim3(256), 0, vfi::as_stream(stream), rgb, lab, N, HW);
+    return vfi::check_launch("vfi_rgb2lab");
+}
+
+extern "C" int vfi_lab2rgb(const float *lab, float *rgb, int N, int HW, vfi_stream_t stream) {
+    VFI_REQUIRE(rgb && lab, VFI_ERR_INVALID_ARG, "vfi_lab2rgb: null pointer");
+    VFI_REQUIRE(N > 0 && HW > 0, VFI_ERR_INVALID_ARG, "vfi_lab2rgb: bad sizes");
+    hipLaunchKernelGGL(lab2rgb_kernel, dim3(blocks_1d((long long)N * HW)), dim3(256), 0, vfi::as_stream(stream), lab, rgb, N, HW);
+    return vfi::check_launch("vfi_lab2rgb");
+}
+
+extern "C" int vfi_channel_mean_diff(const float *a, const float *b, float *out, int N, int C, int HW, float scale,
+                                     int clamp01, vfi_stream_t stream) {
+    VFI_REQUIRE(a && out, VFI_ERR_INVALID_ARG, "vfi_channel_mean_diff: null pointer");
+    VFI_REQUIRE(N > 0 && C > 0 && HW > 0, VFI_ERR_INVALID_ARG, "vfi_channel_mean_diff: bad sizes");
+    hipLaunchKernelGGL(channel_mean_diff_kernel, dim3(blocks_1d((long long)N * HW)), dim3(256), 0, vfi::as_stream(stream), a, b,
+                       out, N, C, HW, scale, clamp01);
+    return vfi::check_launch("vfi_channel_mean_diff");
+}
+
+extern "C" int vfi_absdiff(const float *x, const float *y, float *out, long long count, float scale, int clamp01,
+                           vfi_stream_t stream) {
+    VFI_REQUIRE(x && y && out, VFI_ERR_INVALID_ARG, "vfi_absdiff: null pointer");
+    VFI_REQUIRE(count > 0, VFI_ERR_INVALID_ARG, "vfi_absdiff: bad size");
+    hipLaunchKernelGGL(absdiff_kernel, dim3(blocks_1d(count)), dim3(256), 0, vfi::as_stream(stream), x, y, out, count, scale, clamp01);
+    return vfi::check_launch("vfi_absdiff");
+}
+
+extern "C" int vfi_gaussian_filter(const float *x, float *tmp, float *y, int N, int H, int W, float sigma, float truncate,
+                                   vfi_stream_t stream) {
+    VFI_REQUIRE(x && tmp && y, VFI_ERR_INVALID_ARG, "vfi_gaussian_filter: null pointer");
+    VFI_REQUIRE(N > 0 && H > 0 && W > 0 && sigma > 0 && truncate > 0, VFI_ERR_INVALID_ARG, "vfi_gaussian_filter: bad arguments");
+    GaussTaps t;
+    t.radius = (int)(truncate * sigma + 0.5f);  // scipy: int(truncate * sd + 0.5)
+    VFI_REQUIRE(t.radius <= kMaxRadius, VFI_ERR_UNSUPPORTED, "vfi_gaussian_filter: radius %d > %d", t.radius, kMaxRadius);
+    double sum = 0.0, w[2 * kMaxRadius + 1];
+    for (int k = -t.radius; k <= t.radius; ++k) { w[k + t.radius] = exp(-0.5 / ((double)sigma * sigma) * k * k); sum += w[k + t.radius]; }
+    for (int k = 0; k <= 2 * t.radius; ++k) t.w[k] = (float)(w[k] / sum);
+    hipStream_t s = vfi::as_stream(stream);
+    const long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(gauss_pass_kernel<true>, dim3(blocks_1d(total)), dim3(256), 0, s, x, tmp, N, H, W, t);   // axis 0 first
+    hipLaunchKernelGGL(gauss_pass_kernel<false>, dim3(blocks_1d(total)), dim3(256), 0, s, tmp, y, N, H, W, t);
+    return vfi::check_launch("vfi_gaussian_filter");
+}
+
+extern "C" int vfi_median_filter(const float *x, float *y, int N, int H, int W, int size, vfi_stream_t stream) {
+    VFI_REQUIRE(x && y, VFI_ERR_INVALID_ARG, "vfi_median_filter: null pointer");
+    VFI_REQUIRE(N > 0 && H > 0 && W > 0 && size >= 1, VFI_ERR_INVALID_ARG, "vfi_median_filter: bad arguments");
+    VFI_REQUIRE(size <= 64, VFI_ERR_UNSUPPORTED, "vfi_median_filter: size %d > 64", size);
+    VFI_REQUIRE(N <= 65535, VFI_ERR_UNSUPPORTED, "vfi_median_filter: batch");
+    const size_t lds = (size_t)(kMedTW + size - 1) * (kMedTH + size - 1) * sizeof(unsigned);
+    dim3 grid(ceil_div(W, kMedTW), ceil_div(H, kMedTH), N);
+    hipLaunchKernelGGL(median_kernel, grid, dim3(256), lds, vfi::as_stream(stream), x, y, H, W, size);
+    return vfi::check_launch("vfi_median_filter");
+}

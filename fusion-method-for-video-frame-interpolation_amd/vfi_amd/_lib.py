@@ -34,6 +34,12 @@ SIGNATURES = {
     "vfi_phasenet_emit": [c_f, c_l, c_f, c_l, c_f, c_f, c_f, c_i, c_i, c_s],
     "vfi_phasenet_emit_low": [c_f, c_l, c_f, c_l, c_f, c_f, c_i, c_i, c_s],
     "vfi_tanh_residual_clamp": [c_f, c_f, c_f, c_l, c_s],
+    "vfi_rgb2lab": [c_f, c_f, c_i, c_i, c_s],
+    "vfi_lab2rgb": [c_f, c_f, c_i, c_i, c_s],
+    "vfi_channel_mean_diff": [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_i, c_s],
+    "vfi_absdiff": [c_f, c_f, c_f, c_l, c_fl, c_i, c_s],
+    "vfi_gaussian_filter": [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_s],
+    "vfi_median_filter": [c_f, c_f, c_i, c_i, c_i, c_i, c_s],
     "vfi_pyr_plan_create": [c_i, c_i, c_i, c_i, c_d, c_i, ctypes.POINTER(ctypes.c_void_p)],
     "vfi_pyr_plan_destroy": [ctypes.c_void_p],
     "vfi_pyr_plan_level_size": [ctypes.c_void_p, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i)],

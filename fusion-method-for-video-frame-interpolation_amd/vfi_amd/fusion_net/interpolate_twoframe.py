@@ -1,0 +1,179 @@
+"""Per-frame fused interpolation -- counterpart of reference src/fusion_net/interpolate_twoframe.py.
+
+`interp(args)` keeps the reference's file-in / file-out contract (interpolate_twoframe.py:82-334: PNG paths
+in `args.first_frame` / `second_frame`, centre crop to `args.dim`, outputs written with torchvision's
+`save_image` quantisation, optional `loaded_adacof_model` / `loaded_fusion_net`), so
+src/evaluation/interpolate.py:63-90 can call it unchanged.  The arithmetic lives in `FusionInterpolator`,
+which performs the sequence of interpolate_twoframe.py:148-330 entirely on the MI355X:
+
+  rgb->Lab | AdaCoF #1 | pyramid(6 Lab images) -> PhaseNet -> inverse pyramid -> Lab->rgb |
+  pyramid(ada_pred, rgb_pred) -> two band-limited reconstructions -> uncertainty maps (Gaussian, 50x50 median) |
+  AdaCoF #2,#3 (one batch-2 call) and #4 | [baseline] | FusionNet
+
+Differences from the reference's execution (not its results):
+  * Pyramid, PhaseNet and their plans/weights are built once per frame size, not per frame (:124-137);
+  * no host round trips (the reference leaves the GPU 5x per frame for skimage/scipy, :148-149,190,207-225);
+  * the uncertainty pyramids only transform the levels that are kept (level masks) and both `h_freq`
+    reconstructions run as one batch-6 synthesis;
+  * AdaCoF #2 and #3 are independent and run as one batch of two.
+"""
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..adacof.models import Model
+from ..phase_net.phase_net import PhaseNet
+from ..train.pyramid import Pyramid
+from ..train.utils import calc_pyr_height
+from ..values import DecompValues
+from .fusion_net import FusionNet
+
+DEFAULT_ADACOF_MODEL = "vfi_amd.fusion_net.fusion_adacofnet"
+
+
+def crop_center(img, cropx, cropy):
+    """interpolate_twoframe.py:75-79."""
+    y, x, _ = img.shape
+    startx = x // 2 - (cropx // 2)
+    starty = y // 2 - (cropy // 2)
+    return img[starty:starty + cropy, startx:startx + cropx]
+
+
+def imwrite(tensor, path, range=(0, 1)):
+    """torchvision.utils.save_image for one (3,H,W) image (no normalisation unless asked)."""
+    from PIL import Image
+    arr = tensor.detach().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
+    Image.fromarray(arr).save(path)
+
+
+class FusionInterpolator:
+    """Holds the three networks and the per-size pyramid state; `__call__(rgb1, rgb2)` -> dict of tensors."""
+
+    def __init__(self, adacof_model, fusion_net, phase_net_state=None, device=None):
+        self.adacof = adacof_model
+        self.fusion_net = fusion_net
+        self.device = torch.device(device) if device is not None else next(fusion_net.parameters()).device
+        self.phase_net_state = phase_net_state
+        self._per_size = {}
+
+    def _state(self, h, w):
+        key = (h, w)
+        if key not in self._per_size:
+            height = calc_pyr_height(torch.empty(3, h, w, device="meta"))
+            pyr = Pyramid(height=height, nbands=4, scale_factor=np.sqrt(2), device=self.device)   # :124-129
+            pyr.set_full_size(h, w)
+            net = PhaseNet(pyr, self.device, num_img=2)                                           # :132-137
+            if self.phase_net_state is not None:
+                net.load_state_dict(self.phase_net_state)
+            net.eval()
+            self._per_size[key] = (pyr, net)
+        return self._per_size[key]
+
+    @torch.no_grad()
+    def __call__(self, rgb_frame1, rgb_frame2, output_baseline=False):
+        """rgb_frame1/2: (3,H,W) float32 in [0,1] on the device."""
+        h, w = rgb_frame1.shape[1:]
+        pyr, phase_net = self._state(h, w)
+        nlev = pyr.height - 2
+        lab1, lab2 = ops.rgb2lab(rgb_frame1), ops.rgb2lab(rgb_frame2)                  # :148-149
+        f1, f2 = rgb_frame1.unsqueeze(0), rgb_frame2.unsqueeze(0)
+
+        _, _, ada_pred, flow_var_map = self.adacof(f1, f2)                             # :156  (1,3,H,W), (1,1,H,W)
+
+        # PhaseNet branch (:168-192)
+        vals, bufs = pyr.filter(torch.cat((lab1, lab2), 0), concat_frames=2, phase_scale=1.0 / math.pi)
+        vals_pred = phase_net(phase_net.normalize_vals(vals, concat=bufs))
+        lab_pred = pyr.inv_filter(DecompValues(0, vals_pred.phase, vals_pred.amplitude, vals_pred.low_level))
+        phase_pred = ops.lab2rgb(lab_pred)                                             # (3,H,W) rgb
+
+        # uncertainty maps (:198-225): only the finest and the 6 coarsest band levels are ever used
+        coarse = min(6, nlev)
+        mask = 1 | (((1 << coarse) - 1) << (nlev - coarse))
+        vb = pyr.filter(torch.cat((ada_pred[0], phase_pred), 0), level_mask=mask)      # 6 images, RGB space
+        fine = DecompValues(vb.high_level, [vb.phase[0]] + [0] * (nlev - 1), [vb.amplitude[0]] + [0] * (nlev - 1), 0)
+        hf = pyr.inv_filter(fine)                                                      # (6,H,W): ada | phase
+        d = ops.channel_mean_diff(hf[:3].unsqueeze(0), hf[3:].unsqueeze(0), 100.0, True)   # :207-211
+        phase_uncertainty = ops.gaussian_filter(d, 5)                                  # :212-214  (1,H,W)
+        half = lambda t: (t[:12], t[12:])                                              # ada planes | phase planes
+        dp, da = [0] * nlev, [0] * nlev
+        for k in range(nlev - coarse, nlev):
+            dp[k] = ops.absdiff(*half(vb.phase[k])[::-1])                              # subtract_values(vals_ph, vals_ada)
+            da[k] = ops.absdiff(*half(vb.amplitude[k])[::-1])
+        dlow = ops.absdiff(vb.low_level[3:], vb.low_level[:3])
+        freq = pyr.inv_filter(DecompValues(0, dp, da, dlow))                           # :217-219 (3,H,W)
+        fd = ops.channel_mean_diff(freq.unsqueeze(0), None, 30.0, False)               # :220
+        ada_uncertainty = ops.absdiff(fd, ops.median_filter(fd, 50), 5.0, True)        # :221-225 (1,H,W)
+
+        # baseline (:228-238): AdaCoF on (rgb1, phase_pred), (phase_pred, rgb2), then on the two results
+        pp = phase_pred.unsqueeze(0)
+        _, _, between, _ = self.adacof(torch.cat((f1, pp), 0), torch.cat((pp, f2), 0))
+        _, _, base, _ = self.adacof(between[:1], between[1:])
+
+        out = {"phase_pred": pp, "ada_pred": ada_pred, "base": base, "flow_var_map": flow_var_map,
+               "phase_uncertainty": phase_uncertainty, "ada_uncertainty": ada_uncertainty}
+        if output_baseline:                                                            # :288-322
+            va = pyr.filter(ops.rgb2lab(ada_pred[0]))
+            vp = pyr.filter(ops.rgb2lab(phase_pred))
+            split = nlev // 2
+            mix = DecompValues(va.high_level, vp.phase[:split] + va.phase[split:],
+                               vp.amplitude[:split] + va.amplitude[split:], vp.low_level)
+            out["baseline"] = ops.lab2rgb(pyr.inv_filter(mix)).unsqueeze(0)
+
+        other = torch.cat((lab1, lab2), 0).unsqueeze(0)                                # :324-325 (1,6,H,W)
+        maps = torch.stack((ada_uncertainty, phase_uncertainty, flow_var_map[:, 0]), 1)   # :326-327 (1,3,H,W)
+        out["final"] = self.fusion_net(base, ada_pred, pp, other, maps, variant=0)     # :330
+        return out
+
+
+def build_models(args, device):
+    """The model construction of interpolate_twoframe.py:88-103,139-145 / src/evaluation/evaluate.py:225-242."""
+    if hasattr(args, "loaded_adacof_model"):
+        adacof_model = args.loaded_adacof_model
+    else:
+        adacof_model = Model(SimpleNamespace(gpu_id=args.gpu_id, model=getattr(args, "adacof_model", DEFAULT_ADACOF_MODEL),
+                                             kernel_size=args.adacof_kernel_size, dilation=args.adacof_dilation,
+                                             config=getattr(args, "adacof_config", None)))
+        adacof_model.eval()
+        ckpt = getattr(args, "adacof_checkpoint", None)
+        if ckpt and os.path.exists(ckpt):
+            adacof_model.load(torch.load(ckpt, map_location="cpu")["state_dict"])
+    if hasattr(args, "loaded_fusion_net"):
+        fusion_net = args.loaded_fusion_net
+    else:
+        fusion_net = FusionNet().to(device)
+        fusion_net.load_state_dict(torch.load(args.checkpoint, map_location="cpu"))
+        fusion_net.eval()
+    return adacof_model, fusion_net
+
+
+_INTERPOLATORS = {}
+
+
+def interp(args, high_level=False):
+    """File-based entry point with the reference's argument namespace (interpolate_twoframe.py:82-334)."""
+    from PIL import Image
+    torch.cuda.set_device(args.gpu_id)
+    device = torch.device("cuda:{}".format(args.gpu_id))
+    adacof_model, fusion_net = build_models(args, device)
+    key = (id(adacof_model), id(fusion_net))
+    if key not in _INTERPOLATORS:
+        pn = getattr(args, "phase_net_checkpoint", "./src/phase_net/phase_net.pt")      # :134
+        state = torch.load(pn, map_location="cpu") if pn and os.path.exists(pn) else None
+        _INTERPOLATORS[key] = FusionInterpolator(adacof_model, fusion_net, state, device)
+    runner = _INTERPOLATORS[key]
+    img1 = crop_center(np.array(Image.open(args.first_frame)), args.dim, args.dim)       # :106-113
+    img2 = crop_center(np.array(Image.open(args.second_frame)), args.dim, args.dim)
+    to_t = lambda a: torch.as_tensor(a[..., :3]).permute(2, 0, 1).float().to(device) / 255
+    out = runner(to_t(img1), to_t(img2), output_baseline=getattr(args, "output_baseline", False))
+    if getattr(args, "output_phase", False):
+        imwrite(out["phase_pred"][0], args.output_frame_phase)
+    if getattr(args, "output_adacof", False):
+        imwrite(out["ada_pred"][0], args.output_frame_adacof)
+    if getattr(args, "output_baseline", False):
+        imwrite(out["baseline"][0], args.output_frame_baseline)
+    imwrite(out["final"][0], args.output_frame)
+    return out

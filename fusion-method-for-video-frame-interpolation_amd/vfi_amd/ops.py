@@ -156,3 +156,59 @@ def tanh_residual_clamp(x, base):
     _lib.call("vfi_tanh_residual_clamp", _lib.dptr(x, "x"), _lib.dptr(base, "base"), out.data_ptr(), x.numel(),
               _lib.stream_ptr())
     return out
+
+
+def rgb2lab(rgb):
+    """(N,3,H,W) or (3,H,W) rgb in [0,1] -> scaled Lab, same shape (reference src/train/transform.py:17-25)."""
+    x = rgb.contiguous()
+    hw = x.shape[-1] * x.shape[-2]
+    out = torch.empty_like(x)
+    _lib.call("vfi_rgb2lab", _lib.dptr(x, "rgb"), out.data_ptr(), x.numel() // (3 * hw), hw, _lib.stream_ptr())
+    return out
+
+
+def lab2rgb(lab):
+    x = lab.contiguous()
+    hw = x.shape[-1] * x.shape[-2]
+    out = torch.empty_like(x)
+    _lib.call("vfi_lab2rgb", _lib.dptr(x, "lab"), out.data_ptr(), x.numel() // (3 * hw), hw, _lib.stream_ptr())
+    return out
+
+
+def channel_mean_diff(a, b=None, scale=1.0, clamp01=False):
+    """a, b (N,C,H,W) -> (N,H,W): mean over C of a (minus that of b, abs), * scale, optional clamp."""
+    a = a.contiguous()
+    n, c, h, w = a.shape
+    out = torch.empty((n, h, w), dtype=torch.float32, device=a.device)
+    _lib.call("vfi_channel_mean_diff", _lib.dptr(a, "a"), _lib.dptr(b.contiguous(), "b") if b is not None else None,
+              out.data_ptr(), n, c, h * w, float(scale), int(bool(clamp01)), _lib.stream_ptr())
+    return out
+
+
+def absdiff(x, y, scale=1.0, clamp01=False):
+    x, y = x.contiguous(), y.contiguous()
+    if x.shape != y.shape:
+        raise VfiLibraryError("absdiff: shape mismatch")
+    out = torch.empty_like(x)
+    _lib.call("vfi_absdiff", _lib.dptr(x, "x"), _lib.dptr(y, "y"), out.data_ptr(), x.numel(), float(scale),
+              int(bool(clamp01)), _lib.stream_ptr())
+    return out
+
+
+def gaussian_filter(x, sigma, truncate=4.0):
+    """scipy.ndimage.gaussian_filter per (H,W) image of x (N,H,W)."""
+    x = x.contiguous()
+    n, h, w = x.shape
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    _lib.call("vfi_gaussian_filter", _lib.dptr(x, "x"), tmp.data_ptr(), out.data_ptr(), n, h, w, float(sigma),
+              float(truncate), _lib.stream_ptr())
+    return out
+
+
+def median_filter(x, size):
+    """scipy.ndimage.median_filter(size=size) per (H,W) image of x (N,H,W)."""
+    x = x.contiguous()
+    n, h, w = x.shape
+    out = torch.empty_like(x)
+    _lib.call("vfi_median_filter", _lib.dptr(x, "x"), out.data_ptr(), n, h, w, int(size), _lib.stream_ptr())
+    return out

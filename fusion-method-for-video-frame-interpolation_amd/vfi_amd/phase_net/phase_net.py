@@ -68,7 +68,12 @@ class PhaseNet(PackedModule):
         return out
 
     # -- normalisation (phase_net.py:42-78) -------------------------------------------------------------
-    def normalize_vals(self, vals):
+    def normalize_vals(self, vals, concat=None):
+        """phase_net.py:42-78.  `concat` (from Pyramid.filter(concat_frames=2, phase_scale=1/pi)): the block-input
+        buffers that already hold phase/pi and the raw amplitudes -- then only the maxima are computed and
+        the amplitudes / low level are normalised in place (no copies)."""
+        if concat is not None:
+            return self._normalize_in_place(vals, concat)
         nlev = len(vals.phase)
         b = vals.amplitude[0].shape[0]
         maxes, concat, phases, amps = [], [], [], []
@@ -89,6 +94,19 @@ class PhaseNet(PackedModule):
         self.max_low_level = ops.batch_max(low_in, self.eps)                     # :69
         low = ops.affine_slice(low_in, torch.empty_like(low_in), self.max_low_level, 1.0)   # :70
         out = NormalizedValues(vals.high_level, phases, amps, low)
+        out.concat = concat
+        return out
+
+    def _normalize_in_place(self, vals, concat):
+        maxes = []
+        for idx, amp in enumerate(vals.amplitude):          # views into concat[idx]
+            mx = ops.batch_max(amp, self.eps)
+            maxes.append(mx)
+            ops.affine_slice(amp, amp, mx, 1.0)
+        self.max_amplitudes = maxes
+        self.max_low_level = ops.batch_max(vals.low_level, self.eps)
+        ops.affine_slice(vals.low_level, vals.low_level, self.max_low_level, 1.0)
+        out = NormalizedValues(vals.high_level, list(vals.phase), list(vals.amplitude), vals.low_level)
         out.concat = concat
         return out
 

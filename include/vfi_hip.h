@@ -217,6 +217,35 @@ int vfi_pyr_synthesize(vfi_pyr_plan *plan, const float *high, const float *const
                        const float *const *amp, const int *plane_index, const float *low,
                        unsigned long long level_mask, int flags, float *img, int N, vfi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Image-space stages the reference runs on the host CPU (skimage / scipy round trips)
+ * ---------------------------------------------------------------------------------- */
+
+/* rgb2lab_single / lab2rgb_single (src/train/transform.py:17-25,40-49): skimage D65/2deg conversion
+ * with the reference's scaling L/100, (a+128)/255, (b+128)/255.  (N,3,HW) planar. */
+int vfi_rgb2lab(const float *rgb, float *lab, int N, int HW, vfi_stream_t stream);
+int vfi_lab2rgb(const float *lab, float *rgb, int N, int HW, vfi_stream_t stream);
+
+/* out (N,HW) = mean_c a  (b == NULL)   or   |mean_c a - mean_c b|,  times scale, clamped to [0,1] if clamp01
+ * (src/fusion_net/interpolate_twoframe.py:207-211,219-220: `.mean(1)`, abs, `*100`/`*30`, clamp). */
+int vfi_channel_mean_diff(const float *a, const float *b, float *out, int N, int C, int HW, float scale,
+                          int clamp01, vfi_stream_t stream);
+
+/* out = |x - y| * scale (clamped to [0,1] if clamp01): subtract_values (src/train/utils.py:322-346) and
+ * `abs(freq_diff - median) * 5` clamp (interpolate_twoframe.py:223-224). */
+int vfi_absdiff(const float *x, const float *y, float *out, long long count, float scale, int clamp01,
+                vfi_stream_t stream);
+
+/* scipy.ndimage.gaussian_filter(x, sigma, truncate=truncate) per (H,W) image, mode='reflect'
+ * (interpolate_twoframe.py:212-213 uses sigma=5, default truncate=4 -> 41 taps).  tmp: N*H*W floats. */
+int vfi_gaussian_filter(const float *x, float *tmp, float *y, int N, int H, int W, float sigma, float truncate,
+                        vfi_stream_t stream);
+
+/* scipy.ndimage.median_filter(x, size=size) per (H,W) image: size x size window covering
+ * [i - size/2, i - size/2 + size - 1], mode='reflect', rank size*size/2 (interpolate_twoframe.py:221-222,
+ * size=50).  Exact selection (returns an element of the window). */
+int vfi_median_filter(const float *x, float *y, int N, int H, int W, int size, vfi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
