@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: interpolated frames/s of the full fused per-frame path at 1920x1080.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A step = ONE interpolated frame per rank (the whole sequence of reference
+src/fusion_net/interpolate_twoframe.py:148-330 with output_baseline, as src/evaluation always sets it:
+4x AdaCoF, 4 pyramid analyses, 5 syntheses, PhaseNet, uncertainty maps incl. the 50x50 median, FusionNet)
+on synthetic frame pairs already resident in HBM.  Frames of a clip shard across ranks with no data-path
+collective (weak scaling: fixed work per GPU); weights are broadcast once from rank 0 over RCCL.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "fusion-method-for-video-frame-interpolation_amd")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synthetic_pairs(n_pairs, h, w, device, seed=0):
+    """Band-limited translating textures (oracle.synth is test infrastructure; this is the product-side
+    generator of the same kind of content, built on the device)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    yy, xx = yy.to(device), xx.to(device)
+    pairs = []
+    for p in range(n_pairs):
+        waves = [(float(torch.rand(1, generator=g)) * 0.23 + 0.02, float(torch.rand(1, generator=g)) * np.pi,
+                  float(torch.rand(1, generator=g)) * 2 * np.pi, torch.rand(3, generator=g) * 0.7 + 0.3) for _ in range(6)]
+
+        def render(dy, dx):
+            img = torch.zeros((3, h, w), device=device)
+            for freq, ang, ph, col in waves:
+                arg = freq * np.pi * (np.cos(ang) * (xx - dx) + np.sin(ang) * (yy - dy)) + ph
+                img += col.to(device).view(3, 1, 1) * torch.sin(arg)
+            img = img / 12.0 * 1.2 + 0.5 + 0.15 * ((xx - dx) / w - 0.5) + 0.1 * ((yy - dy) / h - 0.5)
+            return img.clamp_(0, 1).contiguous()
+        pairs.append((render(0.0, 0.0), render(3.5, -2.25)))
+    return pairs
+
+
+def build_runner(device, seed=0):
+    import types
+    from vfi_amd.adacof.models import Model
+    from vfi_amd.fusion_net.fusion_net import FusionNet
+    from vfi_amd.fusion_net.interpolate_twoframe import FusionInterpolator
+    from vfi_amd.phase_net.phase_net import PhaseNet
+    from vfi_amd import shard
+    torch.manual_seed(seed)      # random-init weights of the real architectures (no checkpoints offline)
+    adacof = Model(types.SimpleNamespace(model="vfi_amd.fusion_net.fusion_adacofnet", kernel_size=5, dilation=1,
+                                         gpu_id=device.index or 0))
+    adacof.eval()
+    fusion = FusionNet().to(device)
+    fusion.eval()
+    proto = PhaseNet(types.SimpleNamespace(height=17, nbands=4), device)
+    n = shard.broadcast_module_states([adacof, fusion, proto], src=0)     # RCCL broadcast over xGMI (one buffer)
+    return FusionInterpolator(adacof, fusion, proto.state_dict(), device), n
+
+
+def cpu_baseline(sample_hw=(272, 480), full_hw=(1080, 1920), threads=16):
+    """The oracle pipeline (CPU restatement of the same path) on a bounded sample, scaled by pixel count."""
+    from oracle import pipeline_cpu, synth
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    h, w = sample_hw
+    f0, _, f2 = (torch.from_numpy(x) for x in synth.translating_pair(0, h, w))
+    weights = pipeline_cpu.seeded_weights(0)
+    stages = {}
+    t0 = time.perf_counter()
+    pipeline_cpu.interp(f0, f2, weights, output_baseline=True, timings=stages)
+    t = time.perf_counter() - t0
+    scale = (full_hw[0] * full_hw[1]) / (h * w)
+    return {"value": 1.0 / (t * scale), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"one fused frame at {w}x{h} ({t:.1f} s on {threads} threads), scaled x{scale:.2f} by pixel count to 1920x1080",
+            "stage_seconds": {k: round(v, 3) for k, v in stages.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    from vfi_amd import _lib, shard
+    rank, local_rank, world = shard.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    h, w = args.height, args.width
+
+    runner, n_weights = build_runner(device)
+    pairs = synthetic_pairs(4, h, w, device, seed=rank)
+
+    def step(i):
+        f0, f2 = pairs[i % len(pairs)]
+        return runner(f0, f2, output_baseline=True)["final"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    frames, elapsed = shard.reduce_counters(args.steps, elapsed, device)
+
+    line = None
+    if rank == 0:
+        line = {"metric": "interpolated frames/sec at 1080p", "value": frames / elapsed, "unit": "frames/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"full fused frame (PhaseNet + 4x AdaCoF + uncertainty maps + FusionNet, output_baseline) "
+                                       f"at {w}x{h}, BASELINE.json configs[3]; one frame pair per rank per step",
+                           "frame": [h, w], "weights": f"random-init, {n_weights} params broadcast from rank 0",
+                           "sharding": f"frame pairs over {world} rank(s), no data-path collective"}}
+        if not args.no_profile:
+            # one extra, event-timed frame: per-kernel algorithmic work / measured duration on the launch stream
+            _lib.PROFILE = _lib.Recorder()
+            step(0)
+            agg = _lib.PROFILE.summary()
+            _lib.PROFILE = None
+            convs = {k: v for k, v in agg.items() if v["kind"] == "flop"}
+            dom = max(convs, key=lambda k: convs[k]["seconds"])
+            d = convs[dom]
+            tf = d["work"] / d["seconds"] / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                "launches_per_frame": d["calls"], "avg_launch_ms": d["seconds"] / d["calls"] * 1e3,
+                                "frame_share": d["seconds"] / sum(v["seconds"] for v in agg.values())}
+            line["roofline_other"] = []
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"]):
+                if k == dom or not v["kind"]:
+                    continue
+                rate = v["work"] / v["seconds"]
+                peak, unit, div = (PEAK_FP32_MFMA_TFLOPS, "TFLOP/s", 1e12) if v["kind"] == "flop" else (PEAK_HBM_GBS, "GB/s", 1e9)
+                line["roofline_other"].append({"kernel": k, "bound": "mfma" if v["kind"] == "flop" else "hbm",
+                                               "achieved": rate / div, "peak": peak, "unit": unit, "frac": rate / div / peak,
+                                               "calls": v["calls"], "ms_per_frame": v["seconds"] * 1e3})
+            line["stage_ms"] = {k: round(v["seconds"] * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"])[:12]}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

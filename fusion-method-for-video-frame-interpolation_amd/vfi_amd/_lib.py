@@ -117,5 +117,37 @@ def dptr(t, name="tensor", dtype=None):
     return t.data_ptr()
 
 
-def call(name, *args):
+class Recorder:
+    """Optional per-call timing (HIP events on the launch stream) used by bench.py / tools; off by default.
+    `work` = (kind, amount, label): algorithmic FLOPs ("flop") or bytes ("byte") of the call."""
+
+    def __init__(self):
+        self.rows = []
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        agg = {}
+        for name, work, e0, e1 in self.rows:
+            kind, amount, label = work if work else (None, 0.0, name)
+            a = agg.setdefault(label or name, dict(entry=name, kind=kind, calls=0, seconds=0.0, work=0.0))
+            a["calls"] += 1
+            a["seconds"] += e0.elapsed_time(e1) * 1e-3
+            a["work"] += amount
+        return agg
+
+
+PROFILE = None
+
+
+def call(name, *args, work=None):
+    rec = PROFILE
+    if rec is None:
+        check(getattr(lib(), name)(*args), name)
+        return
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(getattr(lib(), name)(*args), name)
+    e1.record()
+    rec.rows.append((name, work, e0, e1))

@@ -53,5 +53,7 @@ def adacof_fused(frame0, frame2, w1, a1, b1, w2, a2, b2, occ, dilation,
     d = _lib.dptr
     _lib.call("vfi_adacof_fused", d(frame0, "frame0"), d(frame2, "frame2"), d(w1), d(a1), d(b1),
               d(w2), d(a2), d(b2), d(occ), d(t1), d(t2), d(frame), d(mask),
-              n, c, h, w, f, int(dilation), _lib.stream_ptr())
+              n, c, h, w, f, int(dilation), _lib.stream_ptr(),
+              work=("byte", float(n) * h * w * (6 * f * f * 4 + 4 + 2 * 4 * c + 4 * c * (3 if want_sides else 1)
+                                                 + (4 if want_mask else 0)), "adacof_fused_kernel"))
     return t1, t2, frame, mask

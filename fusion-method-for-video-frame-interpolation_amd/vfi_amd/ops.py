@@ -81,8 +81,12 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None):
         if tuple(residual.shape) != tuple(out.shape):
             raise VfiLibraryError("conv2d: residual shape mismatch")
         rp, rs = _slice_ptr(residual, "residual")
+    work = None
+    if _lib.PROFILE is not None:
+        label = f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}>"
+        work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w, label)
     _lib.call("vfi_conv2d", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), rp, rs, yp, ys,
-              n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], _lib.stream_ptr())
+              n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], _lib.stream_ptr(), work=work)
     return out
 
 

@@ -47,20 +47,28 @@ class Plan:
         except Exception:
             pass
 
+    def _bytes(self, n, mask, high, low):
+        """Algorithmic HBM bytes of one transform: image + kept band planes (phase, amp) + residuals."""
+        px = self.h * self.w + (self.h * self.w if high else 0) + (self.sizes[-1][0] * self.sizes[-1][1] if low else 0)
+        px += sum(2 * self.nbands * a * b for k, (a, b) in enumerate(self.sizes[:-1]) if (mask >> k) & 1)
+        return 4.0 * n * px
+
     def analyze(self, img, high, phase, amp, table, low, phase_scale, mask, flags):
         n = img.shape[0]
         tab = (ctypes.c_int * len(table))(*table) if table is not None else None
         _lib.call("vfi_pyr_analyze", self._h, _lib.dptr(img, "img"), n,
                   high.data_ptr() if torch.is_tensor(high) else None, _ptr_array(phase),
                   _ptr_array(amp) if amp is not None else None, tab,
-                  low.data_ptr() if torch.is_tensor(low) else None, float(phase_scale), mask, flags, _lib.stream_ptr())
+                  low.data_ptr() if torch.is_tensor(low) else None, float(phase_scale), mask, flags, _lib.stream_ptr(),
+                  work=("byte", self._bytes(n, mask, torch.is_tensor(high), torch.is_tensor(low)), "pyr_analyze"))
 
     def synthesize(self, high, phase, amp, table, low, mask, flags, img):
         n = img.shape[0]
         tab = (ctypes.c_int * len(table))(*table) if table is not None else None
         _lib.call("vfi_pyr_synthesize", self._h, high.data_ptr() if torch.is_tensor(high) else None,
                   _ptr_array(phase), _ptr_array(amp) if amp is not None else None, tab,
-                  low.data_ptr() if torch.is_tensor(low) else None, mask, flags, img.data_ptr(), n, _lib.stream_ptr())
+                  low.data_ptr() if torch.is_tensor(low) else None, mask, flags, img.data_ptr(), n, _lib.stream_ptr(),
+                  work=("byte", self._bytes(n, mask, torch.is_tensor(high), torch.is_tensor(low)), "pyr_synthesize"))
 
 
 class SCFpyr_PyTorch(object):
