@@ -19,6 +19,8 @@
 //     second moments), so the mask costs no extra HBM traffic.
 #include "vfi_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 using vfi::ceil_div;
@@ -39,10 +41,21 @@ struct Vec<4> {
     }
 };
 
+template <>
+struct Vec<2> {
+    float v[2];
+    __device__ __forceinline__ void load(const float *p) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+
 template <int VEC>
 __device__ __forceinline__ void store_vec(float *p, const float (&v)[VEC]) {
     if constexpr (VEC == 4) {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
     } else {
         p[0] = v[0];
     }
@@ -72,6 +85,26 @@ __device__ __forceinline__ void tap_accumulate(const float *__restrict__ in, siz
         const float v = p[o00] * w00 + p[o10] * w10 + p[o01] * w01 + p[o11] * w11;
         acc[c] += w * v;
     }
+}
+
+// Same tap on a pixel-interleaved frame (H, W, 4 floats: r, g, b, unused): one 16-B gather per corner
+// instead of one 4-B gather per corner and channel (the gathers, not HBM, bound this kernel).
+__device__ __forceinline__ void tap_accumulate_rgbx(const float4 *__restrict__ in, int Hin, int Win, int row,
+                                                    int col, float w, float alpha, float beta, float (&acc)[3]) {
+    const int A = (int)alpha;
+    const int B = (int)beta;
+    const float fa = alpha - (float)A;
+    const float fb = beta - (float)B;
+    const int i0 = min(max(row + A, 0), Hin - 1);
+    const int i1 = min(max(row + A + 1, 0), Hin - 1);
+    const int j0 = min(max(col + B, 0), Win - 1);
+    const int j1 = min(max(col + B + 1, 0), Win - 1);
+    const float ga = 1.0f - fa, gb = 1.0f - fb;
+    const float w00 = ga * gb, w10 = fa * gb, w01 = ga * fb, w11 = fa * fb;
+    const float4 v00 = in[i0 * Win + j0], v10 = in[i1 * Win + j0], v01 = in[i0 * Win + j1], v11 = in[i1 * Win + j1];
+    acc[0] += w * (v00.x * w00 + v10.x * w10 + v01.x * w01 + v11.x * w11);
+    acc[1] += w * (v00.y * w00 + v10.y * w10 + v01.y * w01 + v11.y * w11);
+    acc[2] += w * (v00.z * w00 + v10.z * w10 + v01.z * w01 + v11.z * w11);
 }
 
 // ---- plain forward ------------------------------------------------------------------------
@@ -125,8 +158,8 @@ struct FlowStats {  // pivoted weighted moments of one offset plane (alpha or be
     float m, q;
 };
 
-template <int C, int VEC, int FT>
-__global__ __launch_bounds__(256) void adacof_fused_kernel(
+template <int C, int VEC, int FT, int UNROLL_L, int MIN_WAVES, bool RGBX = false>
+__global__ __launch_bounds__(256, MIN_WAVES) void adacof_fused_kernel(
     const float *__restrict__ frame0, const float *__restrict__ frame2,
     const float *__restrict__ w1, const float *__restrict__ a1, const float *__restrict__ b1,
     const float *__restrict__ w2, const float *__restrict__ a2, const float *__restrict__ b2,
@@ -146,7 +179,7 @@ __global__ __launch_bounds__(256) void adacof_fused_kernel(
     float var[2][VEC];
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
-        const float *__restrict__ in = (side ? frame2 : frame0) + (size_t)n * C * plane;
+        const float *__restrict__ in = (side ? frame2 : frame0) + (size_t)n * (RGBX ? 4 : C) * plane;
         const float *__restrict__ wp = side ? w2 : w1;
         const float *__restrict__ ap = side ? a2 : a1;
         const float *__restrict__ bp = side ? b2 : b1;
@@ -167,9 +200,11 @@ __global__ __launch_bounds__(256) void adacof_fused_kernel(
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { pa[v] = a.v[v]; pb[v] = b.v[v]; }
         }
-#pragma unroll(FT > 0 ? FT : 1)
+        // one row of taps (F loads of w, alpha, beta each) in flight per iteration; a full F*F unroll
+        // exceeds the register file (spills) -- keep the row loop rolled
+#pragma unroll 1
         for (int k = 0; k < F; ++k) {
-#pragma unroll(FT > 0 ? FT : 1)
+#pragma unroll UNROLL_L
             for (int l = 0; l < F; ++l) {
                 const size_t t = tbase + (size_t)(k * F + l) * plane;
                 Vec<VEC> w, a, b;
@@ -178,8 +213,12 @@ __global__ __launch_bounds__(256) void adacof_fused_kernel(
                 b.load(bp + t);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    tap_accumulate<C>(in, plane, H, W, y + k * dil - pad, x0 + v + l * dil - pad,
-                                      w.v[v], a.v[v], b.v[v], res[side][v]);
+                    if constexpr (RGBX)
+                        tap_accumulate_rgbx(reinterpret_cast<const float4 *>(in), H, W, y + k * dil - pad,
+                                            x0 + v + l * dil - pad, w.v[v], a.v[v], b.v[v], res[side][v]);
+                    else
+                        tap_accumulate<C>(in, plane, H, W, y + k * dil - pad, x0 + v + l * dil - pad,
+                                          w.v[v], a.v[v], b.v[v], res[side][v]);
                     const float da = a.v[v] - pa[v], db = b.v[v] - pb[v];
                     s[v] += w.v[v];
                     sa[v].m += w.v[v] * da;
@@ -262,11 +301,11 @@ extern "C" int vfi_adacof_forward(const float *input, const float *weight, const
     return vfi::check_launch("vfi_adacof_forward");
 }
 
-extern "C" int vfi_adacof_fused(const float *frame0, const float *frame2, const float *w1,
-                                const float *a1, const float *b1, const float *w2, const float *a2,
-                                const float *b2, const float *occ, float *out_t1, float *out_t2,
-                                float *out_frame, float *out_mask, int N, int C, int H, int W, int F,
-                                int dilation, vfi_stream_t stream) {
+static int adacof_fused_impl(const float *frame0, const float *frame2, const float *w1,
+                             const float *a1, const float *b1, const float *w2, const float *a2,
+                             const float *b2, const float *occ, float *out_t1, float *out_t2,
+                             float *out_frame, float *out_mask, int N, int C, int H, int W, int F,
+                             int dilation, bool rgbx, vfi_stream_t stream) {
     VFI_REQUIRE(frame0 && frame2 && w1 && a1 && b1 && w2 && a2 && b2 && occ && out_frame,
                 VFI_ERR_INVALID_ARG, "vfi_adacof_fused: null pointer");
     VFI_REQUIRE(N > 0 && H > 0 && W > 0 && F > 0 && dilation > 0, VFI_ERR_INVALID_ARG,
@@ -275,21 +314,57 @@ extern "C" int vfi_adacof_fused(const float *frame0, const float *frame2, const 
     VFI_REQUIRE(((F - 1) * dilation) % 2 == 0, VFI_ERR_SHAPE,
                 "vfi_adacof_fused: (F-1)*dilation must be even (F=%d dilation=%d)", F, dilation);
     VFI_REQUIRE((long long)H * W < (1ll << 31), VFI_ERR_UNSUPPORTED, "vfi_adacof_fused: frame too large");
-    bool vec = (W % 4 == 0) && aligned16(occ) && aligned16(out_frame);
+    bool al16 = aligned16(occ) && aligned16(out_frame);
     for (const void *p : {(const void *)w1, (const void *)a1, (const void *)b1, (const void *)w2,
                           (const void *)a2, (const void *)b2})
-        vec = vec && aligned16(p);
+        al16 = al16 && aligned16(p);
     for (const void *p : {(const void *)out_t1, (const void *)out_t2, (const void *)out_mask})
-        vec = vec && (p == nullptr || aligned16(p));
+        al16 = al16 && (p == nullptr || aligned16(p));
+    static const int variant = getenv("VFI_ADACOF_VARIANT") ? atoi(getenv("VFI_ADACOF_VARIANT")) : 2;  // tuning aid
+    // measured on MI355X at 1088x1920: VEC=1 1.29 ms < VEC=2 1.49 ms < VEC=4 1.95 ms (gather-issue bound)
+    int vec = (al16 && W % 4 == 0) ? 4 : ((al16 && W % 2 == 0) ? 2 : 1);
+    if (variant == 1 && vec == 4) vec = 2;
+    if (variant == 2 || rgbx) vec = 1;
+    if (rgbx) VFI_REQUIRE(aligned16(frame0) && aligned16(frame2), VFI_ERR_INVALID_ARG, "vfi_adacof_fused_rgbx: frames must be 16-B aligned");
     hipStream_t s = vfi::as_stream(stream);
     dim3 block(64, 4);
-    dim3 grid(vfi::ceil_div(W, 64 * (vec ? 4 : 1)), vfi::ceil_div(H, 4), N);
+    dim3 grid(vfi::ceil_div(W, 64 * vec), vfi::ceil_div(H, 4), N);
     VFI_REQUIRE(grid.z <= 65535 && grid.y <= 65535, VFI_ERR_UNSUPPORTED, "vfi_adacof_fused: grid too large");
-#define LAUNCH(VEC, FT)                                                                            \
-    hipLaunchKernelGGL((adacof_fused_kernel<3, VEC, FT>), grid, block, 0, s, frame0, frame2, w1, a1, b1, \
+#define LAUNCH(VEC, FT, UN, MW)                                                                          \
+    hipLaunchKernelGGL((adacof_fused_kernel<3, VEC, FT, UN, MW>), grid, block, 0, s, frame0, frame2, w1, a1, b1, \
                        w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, H, W, F, dilation)
-    if (F == 5) { if (vec) LAUNCH(4, 5); else LAUNCH(1, 5); }
-    else        { if (vec) LAUNCH(4, 0); else LAUNCH(1, 0); }
+    if (rgbx) {
+        if (F == 5)
+            hipLaunchKernelGGL((adacof_fused_kernel<3, 1, 5, 5, 3, true>), grid, block, 0, s, frame0, frame2, w1, a1, b1,
+                               w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, H, W, F, dilation);
+        else
+            hipLaunchKernelGGL((adacof_fused_kernel<3, 1, 0, 1, 4, true>), grid, block, 0, s, frame0, frame2, w1, a1, b1,
+                               w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, H, W, F, dilation);
+    } else if (F == 5) {
+        if (vec == 4) LAUNCH(4, 5, 1, 3);
+        else if (vec == 2) LAUNCH(2, 5, 1, 4);
+        else LAUNCH(1, 5, 5, 3);
+    } else {
+        if (vec == 4) LAUNCH(4, 0, 1, 3); else if (vec == 2) LAUNCH(2, 0, 1, 4); else LAUNCH(1, 0, 1, 4);
+    }
 #undef LAUNCH
     return vfi::check_launch("vfi_adacof_fused");
+}
+
+extern "C" int vfi_adacof_fused(const float *frame0, const float *frame2, const float *w1,
+                                const float *a1, const float *b1, const float *w2, const float *a2,
+                                const float *b2, const float *occ, float *out_t1, float *out_t2,
+                                float *out_frame, float *out_mask, int N, int C, int H, int W, int F,
+                                int dilation, vfi_stream_t stream) {
+    return adacof_fused_impl(frame0, frame2, w1, a1, b1, w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, N, C,
+                             H, W, F, dilation, false, stream);
+}
+
+extern "C" int vfi_adacof_fused_rgbx(const float *frame0_rgbx, const float *frame2_rgbx, const float *w1,
+                                     const float *a1, const float *b1, const float *w2, const float *a2,
+                                     const float *b2, const float *occ, float *out_t1, float *out_t2,
+                                     float *out_frame, float *out_mask, int N, int H, int W, int F,
+                                     int dilation, vfi_stream_t stream) {
+    return adacof_fused_impl(frame0_rgbx, frame2_rgbx, w1, a1, b1, w2, a2, b2, occ, out_t1, out_t2, out_frame,
+                             out_mask, N, 3, H, W, F, dilation, true, stream);
 }

@@ -19,7 +19,7 @@ inline int blocks_for(long long n) {
 // the sampler and emit cat(frame0 - mean, frame2 - mean) (utility.py:86-87, fusion_adacofnet.py:110).
 __global__ void adacof_prepare_kernel(const float *__restrict__ f0, const float *__restrict__ f2,
                                       float *__restrict__ p0, float *__restrict__ p2, float *__restrict__ x6,
-                                      int N, int H, int W, int Hp, int Wp) {
+                                      int N, int H, int W, int Hp, int Wp, int rgbx) {
     const long long total = (long long)N * 3 * Hp * Wp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int x = i % Wp, y = (i / Wp) % Hp, c = (i / ((long long)Wp * Hp)) % 3, n = i / ((long long)Wp * Hp * 3);
@@ -27,9 +27,14 @@ __global__ void adacof_prepare_kernel(const float *__restrict__ f0, const float 
         const size_t s = (((size_t)n * 3 + c) * H + sy) * W + sx;
         const float mean = c == 0 ? 0.4631f : (c == 1 ? 0.4352f : 0.3990f);
         const float a = f0[s], b = f2[s];
-        p0[i] = a;
-        p2[i] = b;
         const size_t plane = (size_t)Hp * Wp, pix = (size_t)y * Wp + x;
+        if (rgbx) {  // pixel-interleaved (N, Hp, Wp, 4) for the sampler's 16-B gathers; 4th float unused
+            p0[((size_t)n * plane + pix) * 4 + c] = a;
+            p2[((size_t)n * plane + pix) * 4 + c] = b;
+        } else {
+            p0[i] = a;
+            p2[i] = b;
+        }
         x6[((size_t)n * 6 + c) * plane + pix] = a - mean;
         x6[((size_t)n * 6 + 3 + c) * plane + pix] = b - mean;
     }
@@ -197,12 +202,12 @@ __global__ void tanh_residual_clamp_kernel(const float *__restrict__ x, const fl
     hipLaunchKernelGGL(kernel, dim3(blocks_for(total)), dim3(kThreads), 0, vfi::as_stream(stream), __VA_ARGS__)
 
 extern "C" int vfi_adacof_prepare(const float *frame0, const float *frame2, float *pad0, float *pad2, float *x6,
-                                  int N, int H, int W, int Hp, int Wp, vfi_stream_t stream) {
+                                  int N, int H, int W, int Hp, int Wp, int rgbx, vfi_stream_t stream) {
     VFI_REQUIRE(frame0 && frame2 && pad0 && pad2 && x6, VFI_ERR_INVALID_ARG, "vfi_adacof_prepare: null pointer");
     VFI_REQUIRE(N > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W, VFI_ERR_INVALID_ARG, "vfi_adacof_prepare: bad sizes");
     VFI_REQUIRE(Hp - H < H && Wp - W < W, VFI_ERR_SHAPE, "vfi_adacof_prepare: reflect pad %dx%d needs a larger frame than %dx%d",
                 Hp - H, Wp - W, H, W);
-    LAUNCH_1D(adacof_prepare_kernel, (long long)N * 3 * Hp * Wp, stream, frame0, frame2, pad0, pad2, x6, N, H, W, Hp, Wp);
+    LAUNCH_1D(adacof_prepare_kernel, (long long)N * 3 * Hp * Wp, stream, frame0, frame2, pad0, pad2, x6, N, H, W, Hp, Wp, rgbx);
     return vfi::check_launch("vfi_adacof_prepare");
 }
 

@@ -42,6 +42,11 @@ struct ConvArgs {
     int act;       // vfi_act
 };
 
+// Padding / channel-tail elements of the input tile are loaded from here instead of being selected to zero
+// after the load: a select would make the loaded value "used" right away and force s_waitcnt vmcnt(0)
+// BEFORE the chunk's MFMAs, i.e. no overlap of the prefetch with compute.
+__device__ float g_zero_word = 0.0f;   // (non-const: stays in the global address space -> global_load, not flat_load)
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case 1: return fmaxf(v, 0.0f);
@@ -63,10 +68,12 @@ struct ConvTile {
     static constexpr int TH = 8, TW = 32, PADK = (KS - 1) / 2;
     static constexpr int R = TH + KS - 1, PW = TW + KS - 1, PLANE = R * PW, TAPS = KS * KS, BN = 32 * NT;
     static constexpr int IN_ELEMS = CK * PLANE;
+    static constexpr int IN_ELEMS_PAD = (IN_ELEMS + 3) / 4 * 4;  // keeps the weight slab 16-B aligned
     static constexpr int W_ELEMS = CK * TAPS * BN;
     static constexpr int IN_PER_THREAD = (IN_ELEMS + 255) / 256;
     static constexpr int W4_PER_THREAD = (W_ELEMS / 4 + 255) / 256;
-    static constexpr int BUF = IN_ELEMS + W_ELEMS;
+    static constexpr int W_ALLOC = (W_ELEMS + 255) / 256 * 256;   // LDS-DMA writes whole 1-KiB wave pieces
+    static constexpr int BUF = IN_ELEMS_PAD + W_ALLOC;
     static constexpr size_t LDS_BYTES = 2ull * BUF * sizeof(float);
 };
 
@@ -107,37 +114,41 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
     const float *wn = a.wp + (size_t)nb * T::BN;
 
     float in_reg[T::IN_PER_THREAD];
-    float4 w_reg[T::W4_PER_THREAD];
 
-    auto load_chunk = [&](int ch) {
+    // Input tile: global -> registers (branch-free: every load is issued unconditionally from a valid
+    // address and the value selected afterwards, so all loads of a chunk are in flight together and the
+    // staging array stays in VGPRs) -> LDS after the chunk's MFMAs.
+    auto load_inputs = [&](int ch) {
         const float *xc = xn + (size_t)ch * CK * HW;
         const int cbase = ch * CK;
 #pragma unroll
         for (int i = 0; i < T::IN_PER_THREAD; ++i) {
             const bool ok = in_off[i] >= 0 && (cbase + in_c[i]) < a.Cin;
-            in_reg[i] = ok ? xc[in_off[i]] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < T::W4_PER_THREAD; ++i) {
-            const int f = tid + 256 * i;
-            if (T::W_ELEMS / 4 % 256 == 0 || f < T::W_ELEMS / 4) {
-                const int row = f / (T::BN / 4), col4 = f % (T::BN / 4);
-                w_reg[i] = *reinterpret_cast<const float4 *>(
-                    wn + ((size_t)ch * CK * T::TAPS + row) * a.Cout_pad + col4 * 4);
-            }
+            const float *p = ok ? xc + in_off[i] : &g_zero_word;
+            in_reg[i] = *p;
         }
     };
-    auto store_chunk = [&](float *buf) {
+    auto store_inputs = [&](float *buf) {
 #pragma unroll
         for (int i = 0; i < T::IN_PER_THREAD; ++i) {
             const int e = tid + 256 * i;
             if (T::IN_ELEMS % 256 == 0 || e < T::IN_ELEMS) buf[e] = in_reg[i];
         }
-        float4 *wb = reinterpret_cast<float4 *>(buf + T::IN_ELEMS);
+    };
+    // Weight slab: global -> LDS directly (LDS-DMA, 16 B per lane = 1 KiB per wave-instruction, no staging
+    // registers, no ds_write pass).  The slab is linear in LDS in exactly the order the lanes are numbered.
+    auto load_weights_async = [&](int ch, float *buf) {
+        float *wb = buf + T::IN_ELEMS_PAD;
 #pragma unroll
         for (int i = 0; i < T::W4_PER_THREAD; ++i) {
-            const int f = tid + 256 * i;
-            if (T::W_ELEMS / 4 % 256 == 0 || f < T::W_ELEMS / 4) wb[f] = w_reg[i];
+            const int f0 = 256 * i + wave * 64;               // wave-uniform first float4 of this piece
+            if (f0 < T::W_ELEMS / 4) {
+                const int f = min(f0 + lane, T::W_ELEMS / 4 - 1);
+                const int row = f / (T::BN / 4), col4 = f % (T::BN / 4);
+                const float *g = wn + ((size_t)ch * CK * T::TAPS + row) * a.Cout_pad + col4 * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(wb + f0 * 4), 16, 0, 0);
+            }
         }
     };
 
@@ -150,8 +161,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
             for (int q = 0; q < 16; ++q) acc[nt][rr][q] = 0.0f;
 
     const int nchunks = a.Cin_pad / CK;
-    load_chunk(0);
-    store_chunk(lds);
+    load_weights_async(0, lds);
+    load_inputs(0);
+    store_inputs(lds);
     __syncthreads();
 
     const int b_base = khalf * T::PLANE + (2 * wave) * T::PW + l31;
@@ -159,35 +171,56 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const float *buf = lds + (ch & 1) * T::BUF;
-        if (ch + 1 < nchunks) load_chunk(ch + 1);
-        const float *in_s = buf + b_base;
-        const float *w_s = buf + T::IN_ELEMS + a_base;
-#pragma unroll
-        for (int c2 = 0; c2 < CK / 2; ++c2) {
-#pragma unroll
-            for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    float bf[2], af[NT];
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) bf[rr] = in_s[2 * c2 * T::PLANE + (rr + ky) * T::PW + kx];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        af[nt] = w_s[(2 * c2 * T::TAPS + ky * KS + kx) * T::BN + nt * 32];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int rr = 0; rr < 2; ++rr)
-                            acc[nt][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[nt], bf[rr], acc[nt][rr], 0, 0, 0);
-                }
-            }
+        if (ch + 1 < nchunks) {
+            load_weights_async(ch + 1, lds + ((ch + 1) & 1) * T::BUF);
+            load_inputs(ch + 1);
         }
-        if (ch + 1 < nchunks) store_chunk(lds + ((ch + 1) & 1) * T::BUF);
+        const float *in_s = buf + b_base;
+        const float *w_s = buf + T::IN_ELEMS_PAD + a_base;
+        // K loop over (channel pair, tap), fully unrolled; fragments of step s+1 are read from LDS while the
+        // MFMAs of step s issue (explicit two-deep register pipeline).  Pairs beyond the real Cin (tail of
+        // the last chunk) are skipped: their weights are zero.
+        constexpr int NSTEP = (CK / 2) * T::TAPS;
+        const int valid_pairs = min(CK / 2, (a.Cin - ch * CK + 1) / 2);
+        float af[2][NT], bf[2][2];
+        auto frag = [&](int sidx, float (&fa)[NT], float (&fb)[2]) {
+            const int c2 = sidx / T::TAPS, tap = sidx % T::TAPS, ky = tap / KS, kx = tap % KS;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) fb[rr] = in_s[2 * c2 * T::PLANE + (rr + ky) * T::PW + kx];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fa[nt] = w_s[(2 * c2 * T::TAPS + tap) * T::BN + nt * 32];
+        };
+        frag(0, af[0], bf[0]);
+#pragma unroll
+        for (int sidx = 0; sidx < NSTEP; ++sidx) {
+            if (sidx % T::TAPS == 0 && sidx / T::TAPS >= valid_pairs) break;   // wave-uniform
+            if (sidx + 1 < NSTEP) frag(sidx + 1, af[(sidx + 1) & 1], bf[(sidx + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    acc[nt][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sidx & 1][nt], bf[sidx & 1][rr], acc[nt][rr], 0, 0, 0);
+        }
+        if (ch + 1 < nchunks) store_inputs(lds + ((ch + 1) & 1) * T::BUF);
         __syncthreads();
     }
 
     // ---- epilogue: bias + activation (+ residual), 128-B row segments per store ------------------
+    // All bias / residual loads of a 32x32 tile are issued together before the first store (a load inside
+    // the store loop is waited for individually: 16*NT serialized round trips per lane).
     const int gx = x0 + l31;
+    const float *__restrict__ biasp = a.bias;
+    const float *__restrict__ resp = a.res ? a.res + (size_t)n * a.res_bs : nullptr;
+    float *__restrict__ yp = a.y + (size_t)n * a.y_bs;
+    float bv[NT][16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = nb * T::BN + nt * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+            bv[nt][q] = biasp ? biasp[min(co, a.Cout - 1)] : 0.0f;
+        }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int gy = y0 + 2 * wave + rr;
@@ -195,17 +228,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
         const size_t pix = (size_t)gy * a.W + gx;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            float rv[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int co = nb * T::BN + nt * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
-                if (co < a.Cout) {
-                    float v = acc[nt][rr][q];
-                    if (a.bias) v += a.bias[co];
-                    v = apply_act(v, a.act);
-                    const size_t o = (size_t)co * HW + pix;
-                    if (a.res) v += a.res[(size_t)n * a.res_bs + o];
-                    a.y[(size_t)n * a.y_bs + o] = v;
-                }
+                rv[q] = resp ? resp[(size_t)min(co, a.Cout - 1) * HW + pix] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = nb * T::BN + nt * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+                if (co < a.Cout) yp[(size_t)co * HW + pix] = apply_act(acc[nt][rr][q] + bv[nt][q], a.act) + rv[q];
             }
         }
     }

@@ -139,10 +139,10 @@ class AdaCoFNet(torch.nn.Module):
         h0, w0 = int(frame0.shape[2]), int(frame0.shape[3])
         if h0 != int(frame2.shape[2]) or w0 != int(frame2.shape[3]):
             sys.exit("Frame sizes do not match")                                 # fusion_adacofnet.py:177-178
-        pad0, pad2, x6 = ops.adacof_prepare(frame0.contiguous(), frame2.contiguous())
+        pad0, pad2, x6 = ops.adacof_prepare(frame0.contiguous(), frame2.contiguous(), rgbx=True)
         w1, a1, b1, w2, a2, b2, occ = self.get_kernel.forward_x6(x6)
-        t1, t2, frame1, mask = adacof_fused(pad0, pad2, w1, a1, b1, w2, a2, b2, occ, self.dilation)
-        if pad0.shape[2] != h0 or pad0.shape[3] != w0:
+        t1, t2, frame1, mask = adacof_fused(pad0, pad2, w1, a1, b1, w2, a2, b2, occ, self.dilation, rgbx=True)
+        if x6.shape[2] != h0 or x6.shape[3] != w0:
             # the reference's width crop assigns tensorAdaCoF1 from tensorAdaCoF2 (fusion_adacofnet.py:225);
             # both are unused downstream -- we return the correctly cropped t1.
             t1, t2, frame1, mask = (t[:, :, :h0, :w0].contiguous() for t in (t1, t2, frame1, mask))

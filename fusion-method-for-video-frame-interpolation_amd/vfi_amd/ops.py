@@ -90,15 +90,17 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None):
     return out
 
 
-def adacof_prepare(frame0, frame2):
-    """-> (pad0, pad2 (N,3,Hp,Wp), x6 (N,6,Hp,Wp)); Hp, Wp = sizes rounded up to multiples of 32."""
+def adacof_prepare(frame0, frame2, rgbx=True):
+    """-> (pad0, pad2, x6 (N,6,Hp,Wp)); Hp, Wp = sizes rounded up to multiples of 32.  pad0/pad2 are the
+    reflect-padded raw frames: pixel-interleaved (N,Hp,Wp,4) when rgbx, else planar (N,3,Hp,Wp)."""
     n, c, h, w = frame0.shape
     if c != 3 or tuple(frame2.shape) != tuple(frame0.shape):
         raise VfiLibraryError("adacof_prepare: frames must both be (N,3,H,W)")
     hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
-    pad0, pad2, x6 = new((n, 3, hp, wp), frame0), new((n, 3, hp, wp), frame0), new((n, 6, hp, wp), frame0)
+    shape = (n, hp, wp, 4) if rgbx else (n, 3, hp, wp)
+    pad0, pad2, x6 = new(shape, frame0), new(shape, frame0), new((n, 6, hp, wp), frame0)
     _lib.call("vfi_adacof_prepare", _lib.dptr(frame0, "frame0"), _lib.dptr(frame2, "frame2"), pad0.data_ptr(),
-              pad2.data_ptr(), x6.data_ptr(), n, h, w, hp, wp, _lib.stream_ptr())
+              pad2.data_ptr(), x6.data_ptr(), n, h, w, hp, wp, int(bool(rgbx)), _lib.stream_ptr())
     return pad0, pad2, x6
 
 

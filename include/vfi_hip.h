@@ -81,6 +81,15 @@ int vfi_adacof_fused(const float *frame0, const float *frame2,
                      float *out_t1, float *out_t2, float *out_frame, float *out_mask,
                      int N, int C, int H, int W, int F, int dilation, vfi_stream_t stream);
 
+/* Same computation on PIXEL-INTERLEAVED frames (N, H, W, 4) = (r, g, b, unused), as written by
+ * vfi_adacof_prepare(..., rgbx=1): one 16-byte gather per bilinear corner instead of three 4-byte ones
+ * (the kernel is bound by gather issue, not by HBM).  Outputs stay planar (N, 3, H, W). */
+int vfi_adacof_fused_rgbx(const float *frame0_rgbx, const float *frame2_rgbx,
+                          const float *w1, const float *a1, const float *b1,
+                          const float *w2, const float *a2, const float *b2, const float *occ,
+                          float *out_t1, float *out_t2, float *out_frame, float *out_mask,
+                          int N, int H, int W, int F, int dilation, vfi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Dense convolution on the fp32 matrix cores (exact fp32, v_mfma_f32_32x32x2_f32)
  * ---------------------------------------------------------------------------------- */
@@ -123,9 +132,10 @@ int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const
 
 /* AdaCoFNet.forward prologue (src/fusion_net/fusion_adacofnet.py:182-193, src/adacof/utility.py:86-87):
  * reflect-pads both (N,3,H,W) frames at the bottom/right to (Hp,Wp) (multiples of 32), writes the padded
- * raw frames pad0/pad2 (N,3,Hp,Wp) for the sampler and x6 = cat(pad0 - mean, pad2 - mean) (N,6,Hp,Wp). */
+ * raw frames pad0/pad2 for the sampler -- planar (N,3,Hp,Wp) when rgbx == 0, pixel-interleaved (N,Hp,Wp,4)
+ * when rgbx == 1 (4th float left untouched) -- and x6 = cat(pad0 - mean, pad2 - mean) (N,6,Hp,Wp). */
 int vfi_adacof_prepare(const float *frame0, const float *frame2, float *pad0, float *pad2, float *x6, int N,
-                       int H, int W, int Hp, int Wp, vfi_stream_t stream);
+                       int H, int W, int Hp, int Wp, int rgbx, vfi_stream_t stream);
 
 /* 2x2 / stride-2 pooling, floor output size.  is_max=0: AvgPool2d (fusion_adacofnet.py:76-89);
  * is_max=1: MaxPool2d (src/fusion_net/fusion_net.py:41,59). */

@@ -128,3 +128,24 @@ def test_shape_errors_mirror_reference_asserts(device):
         FunctionAdaCoF.apply(x, w, w, w, 1)
     with pytest.raises(AssertionError):     # adacof.py:329 (non-contiguous)
         FunctionAdaCoF.apply(torch.zeros(1, 3, 8, 16, device=device)[:, :, :, ::2], w, w, w, 1)
+
+
+def test_fused_rgbx_equals_planar(device):
+    # the pixel-interleaved variant (16-B gathers) computes exactly the same sums
+    from vfi_amd import ops
+    c = _rand_case(21, 2, 40, 72, 5)
+    d = {k: _dev(v, device) for k, v in c.items()}
+    ref = adacof_fused(d["f0"], d["f2"], d["w1"], d["a1"], d["b1"], d["w2"], d["a2"], d["b2"], d["occ"], 1)
+    inter = lambda f: torch.cat((f, torch.full_like(f[:, :1], float("nan"))), 1).permute(0, 2, 3, 1).contiguous()
+    got = adacof_fused(inter(d["f0"]), inter(d["f2"]), d["w1"], d["a1"], d["b1"], d["w2"], d["a2"], d["b2"], d["occ"], 1,
+                       rgbx=True)
+    for a, b in zip(ref, got):
+        assert (a - b).abs().max().item() <= 1e-6
+    # and the prologue writes that layout (reflect pad to /32 + mean-subtracted concat)
+    f0, f2 = d["f0"][:, :, :, :70].contiguous(), d["f2"][:, :, :, :70].contiguous()
+    p0, p2, x6 = ops.adacof_prepare(f0, f2, rgbx=True)
+    q0, q2, y6 = ops.adacof_prepare(f0, f2, rgbx=False)
+    assert p0.shape == (2, 64, 96, 4) and q0.shape == (2, 3, 64, 96) and torch.equal(x6, y6)
+    assert torch.equal(p0[..., :3].permute(0, 3, 1, 2), q0) and torch.equal(p2[..., :3].permute(0, 3, 1, 2), q2)
+    want = torch.nn.functional.pad(torch.nn.functional.pad(f0, (0, 0, 0, 24), mode="reflect"), (0, 26, 0, 0), mode="reflect")
+    assert torch.equal(q0, want)

@@ -50,19 +50,45 @@ def conv_cases():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="conv")
+    ap.add_argument("--filter", default="")
+    ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.what == "adacof":
+        bench_adacof(dev)
     if args.what == "conv":
         tot_f, tot_t = 0.0, 0.0
         for name, n, cin, cout, h, w, ks, pad in conv_cases():
+            if args.filter and args.filter not in name:
+                continue
             x = torch.randn((n, cin, h, w), device=dev)
             pc = ops.PackedConv(torch.randn(cout, cin, ks, ks) / (cin * ks * ks) ** 0.5, torch.zeros(cout), device=dev)
             out = torch.empty((n, cout, h, w), device=dev)
-            t = timeit(lambda: ops.conv2d(x, pc, pad, "relu", out=out))
+            t = timeit(lambda: ops.conv2d(x, pc, pad, "relu", out=out), iters=args.iters)
             fl = 2.0 * n * cin * cout * ks * ks * h * w
             tot_f += fl; tot_t += t
             print(f"{name:28s} {t*1e3:8.3f} ms  {fl/t/1e12:7.2f} TFLOP/s", flush=True)
         print(f"{'total':28s} {tot_t*1e3:8.3f} ms  {tot_f/tot_t/1e12:7.2f} TFLOP/s")
+
+
+def bench_adacof(dev):
+    from vfi_amd.adacof.cupy_module.adacof import adacof_fused
+    n, h, w = 1, 1088, 1920
+    g = torch.Generator(device="cpu").manual_seed(1)
+    f0 = torch.rand((n, 3, h, w), generator=g).to(dev)
+    f2 = torch.rand((n, 3, h, w), generator=g).to(dev)
+    W = torch.softmax(torch.randn((2, n, 25, h, w), generator=g), 2).to(dev).contiguous()
+    a = (torch.randn((4, n, 25, h, w), generator=g) * 2).clamp(-8, 8).to(dev)
+    occ = torch.rand((n, 1, h, w), generator=g).to(dev)
+    x0 = torch.cat((f0, f0[:, :1]), 1).permute(0, 2, 3, 1).contiguous()
+    x2 = torch.cat((f2, f2[:, :1]), 1).permute(0, 2, 3, 1).contiguous()
+    t = timeit(lambda: adacof_fused(x0, x2, W[0], a[0], a[1], W[1], a[2], a[3], occ, 1, True, True, rgbx=True))
+    by = n * h * w * (150 * 4 + 4 + 24 + 36 + 4)
+    print(f"adacof_fused_rgbx 1088x1920: {t*1e3:.3f} ms  {by/t/1e9:.0f} GB/s ({by/t/8e12*100:.1f}% of 8 TB/s)", flush=True)
+    for sides, mask in ((True, True), (False, False)):
+        t = timeit(lambda: adacof_fused(f0, f2, W[0], a[0], a[1], W[1], a[2], a[3], occ, 1, sides, mask))
+        by = n * h * w * (150 * 4 + 4 + 24 + 12 * (3 if sides else 1) + (4 if mask else 0))
+        print(f"adacof_fused 1088x1920 sides={sides} mask={mask}: {t*1e3:.3f} ms  {by/t/1e9:.0f} GB/s ({by/t/8e12*100:.1f}% of 8 TB/s)", flush=True)
 
 
 if __name__ == "__main__":
