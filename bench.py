@@ -51,7 +51,7 @@ def synthetic_pairs(n_pairs, h, w, device, seed=0):
     return pairs
 
 
-def build_runner(device, seed=0):
+def build_runner(device, n_streams=1, seed=0):
     import types
     from vfi_amd.adacof.models import Model
     from vfi_amd.fusion_net.fusion_net import FusionNet
@@ -66,7 +66,9 @@ def build_runner(device, seed=0):
     fusion.eval()
     proto = PhaseNet(types.SimpleNamespace(height=17, nbands=4), device)
     n = shard.broadcast_module_states([adacof, fusion, proto], src=0)     # RCCL broadcast over xGMI (one buffer)
-    return FusionInterpolator(adacof, fusion, proto.state_dict(), device), n
+    state = proto.state_dict()
+    # one interpolator (own pyramid plan / workspace / PhaseNet state) per in-flight frame; weights are shared
+    return [FusionInterpolator(adacof, fusion, state, device) for _ in range(n_streams)], n
 
 
 def cpu_baseline(sample_hw=(272, 480), full_hw=(1080, 1920), threads=16):
@@ -94,6 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="frames in flight per GPU (independent frames of the clip on separate HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -106,12 +110,18 @@ def main():
     device = torch.device("cuda", local_rank)
     h, w = args.height, args.width
 
-    runner, n_weights = build_runner(device)
+    runners, n_weights = build_runner(device, args.streams)
+    streams = [torch.cuda.Stream(device=device) for _ in runners]
     pairs = synthetic_pairs(4, h, w, device, seed=rank)
+    torch.cuda.synchronize()
 
     def step(i):
+        # frames of a clip are independent: frame i runs on stream i % S, so one frame's small kernels
+        # (coarse pyramid levels, deep U-Net levels) overlap with another frame's large ones
         f0, f2 = pairs[i % len(pairs)]
-        return runner(f0, f2, output_baseline=True)["final"]
+        k = i % len(runners)
+        with torch.cuda.stream(streams[k]):
+            return runners[k](f0, f2, output_baseline=True)["final"]
 
     def barrier():
         if world > 1:
@@ -136,11 +146,14 @@ def main():
                 "config": {"workload": f"full fused frame (PhaseNet + 4x AdaCoF + uncertainty maps + FusionNet, output_baseline) "
                                        f"at {w}x{h}, BASELINE.json configs[3]; one frame pair per rank per step",
                            "frame": [h, w], "weights": f"random-init, {n_weights} params broadcast from rank 0",
-                           "sharding": f"frame pairs over {world} rank(s), no data-path collective"}}
+                           "sharding": f"frame pairs over {world} rank(s), no data-path collective",
+                           "frames_in_flight_per_gpu": args.streams}}
         if not args.no_profile:
             # one extra, event-timed frame: per-kernel algorithmic work / measured duration on the launch stream
+            torch.cuda.synchronize()
             _lib.PROFILE = _lib.Recorder()
-            step(0)
+            f0, f2 = pairs[0]
+            runners[0](f0, f2, output_baseline=True)          # one frame alone on the default stream
             agg = _lib.PROFILE.summary()
             _lib.PROFILE = None
             convs = {k: v for k, v in agg.items() if v["kind"] == "flop"}

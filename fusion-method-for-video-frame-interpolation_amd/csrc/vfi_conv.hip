@@ -40,6 +40,8 @@ struct ConvArgs {
     int Cin, Cin_pad, Cout, Cout_pad, H, W, tiles_x;
     int pad_mode;  // 0 zero, 1 reflect
     int act;       // vfi_act
+    int Hs, Ws;    // UPS kernels: size of the low-resolution source x (H = 2*Hs, W = 2*Ws)
+    float ups_sy, ups_sx;   // (Hs-1)/(H-1), (Ws-1)/(W-1): torch bilinear, align_corners=True
 };
 
 // Padding / channel-tail elements of the input tile are loaded from here instead of being selected to zero
@@ -77,7 +79,9 @@ struct ConvTile {
     static constexpr size_t LDS_BYTES = 2ull * BUF * sizeof(float);
 };
 
-template <int KS, int CK, int NT>
+// UPS: the conv input is nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)(x) and is never
+// materialised -- the tile loader interpolates it from the low-resolution x (4 loads + lerp per element).
+template <int KS, int CK, int NT, bool UPS = false>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
     using T = ConvTile<KS, CK, NT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -107,32 +111,58 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
         } else {
             ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         }
-        in_off[i] = ok ? c * HW + gy * a.W + gx : -1;
+        if (UPS) in_off[i] = ok ? ((gy << 16) | gx) : -1;     // packed output-grid coordinates
+        else     in_off[i] = ok ? c * HW + gy * a.W + gx : -1;
         in_c[i] = c;
     }
+    const int HWs = UPS ? a.Hs * a.Ws : HW;   // channel stride of x
     const float *xn = a.x + (size_t)n * a.x_bs;
     const float *wn = a.wp + (size_t)nb * T::BN;
 
-    float in_reg[T::IN_PER_THREAD];
+    float in_reg[UPS ? 4 : 1][T::IN_PER_THREAD];
 
     // Input tile: global -> registers (branch-free: every load is issued unconditionally from a valid
     // address and the value selected afterwards, so all loads of a chunk are in flight together and the
     // staging array stays in VGPRs) -> LDS after the chunk's MFMAs.
     auto load_inputs = [&](int ch) {
-        const float *xc = xn + (size_t)ch * CK * HW;
+        const float *xc = xn + (size_t)ch * CK * HWs;
         const int cbase = ch * CK;
 #pragma unroll
         for (int i = 0; i < T::IN_PER_THREAD; ++i) {
             const bool ok = in_off[i] >= 0 && (cbase + in_c[i]) < a.Cin;
-            const float *p = ok ? xc + in_off[i] : &g_zero_word;
-            in_reg[i] = *p;
+            if constexpr (UPS) {
+                // always-valid addresses (coordinates / channel clamped), 32-bit offsets from the wave-uniform
+                // sample base; padding and the channel tail are zeroed when the tile is written to LDS
+                const int pk = max(in_off[i], 0);
+                const int gy = pk >> 16, gx = pk & 0xffff;
+                const int sy0 = (int)(a.ups_sy * (float)gy), sx0 = (int)(a.ups_sx * (float)gx);
+                const int sy1 = min(sy0 + 1, a.Hs - 1), sx1 = min(sx0 + 1, a.Ws - 1);
+                const int cb = min(cbase + in_c[i], a.Cin - 1) * HWs;
+                in_reg[0][i] = xn[cb + sy0 * a.Ws + sx0];
+                in_reg[1][i] = xn[cb + sy0 * a.Ws + sx1];
+                in_reg[2][i] = xn[cb + sy1 * a.Ws + sx0];
+                in_reg[3][i] = xn[cb + sy1 * a.Ws + sx1];
+            } else {
+                const float *p = ok ? xc + in_off[i] : &g_zero_word;
+                in_reg[0][i] = *p;
+            }
         }
     };
-    auto store_inputs = [&](float *buf) {
+    auto store_inputs = [&](float *buf, int ch) {
 #pragma unroll
         for (int i = 0; i < T::IN_PER_THREAD; ++i) {
             const int e = tid + 256 * i;
-            if (T::IN_ELEMS % 256 == 0 || e < T::IN_ELEMS) buf[e] = in_reg[i];
+            float v = in_reg[0][i];
+            if constexpr (UPS) {   // torch upsample_bilinear2d: h0l*(w0l*v00 + w1l*v01) + h1l*(w0l*v10 + w1l*v11)
+                const int pk = max(in_off[i], 0);
+                const int gy = pk >> 16, gx = pk & 0xffff;
+                const float fy = a.ups_sy * (float)gy, fx = a.ups_sx * (float)gx;
+                const float ly = fy - (float)(int)fy, lx = fx - (float)(int)fx;
+                v = (1.0f - ly) * ((1.0f - lx) * in_reg[0][i] + lx * in_reg[1][i]) +
+                    ly * ((1.0f - lx) * in_reg[2][i] + lx * in_reg[3][i]);
+                v = (in_off[i] >= 0 && ch * CK + in_c[i] < a.Cin) ? v : 0.0f;
+            }
+            if (T::IN_ELEMS % 256 == 0 || e < T::IN_ELEMS) buf[e] = v;
         }
     };
     // Weight slab: global -> LDS directly (LDS-DMA, 16 B per lane = 1 KiB per wave-instruction, no staging
@@ -163,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
     const int nchunks = a.Cin_pad / CK;
     load_weights_async(0, lds);
     load_inputs(0);
-    store_inputs(lds);
+    store_inputs(lds, 0);
     __syncthreads();
 
     const int b_base = khalf * T::PLANE + (2 * wave) * T::PW + l31;
@@ -202,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
                 for (int rr = 0; rr < 2; ++rr)
                     acc[nt][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sidx & 1][nt], bf[sidx & 1][rr], acc[nt][rr], 0, 0, 0);
         }
-        if (ch + 1 < nchunks) store_inputs(lds + ((ch + 1) & 1) * T::BUF);
+        if (ch + 1 < nchunks) store_inputs(lds + ((ch + 1) & 1) * T::BUF, ch + 1);
         __syncthreads();
     }
 
@@ -263,19 +293,19 @@ __global__ void conv2d_pack_kernel(const float *__restrict__ w, const float *__r
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int KS, int CK, int NT>
+template <int KS, int CK, int NT, bool UPS = false>
 int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
     using T = ConvTile<KS, CK, NT>;
     static bool attr_done = false;  // idempotent; racing threads set the same value
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_mfma_kernel<KS, CK, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_mfma_kernel<KS, CK, NT, UPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
         if (e != hipSuccess) return vfi::fail(VFI_ERR_LAUNCH, "vfi_conv2d: set LDS size: %s", hipGetErrorString(e));
         attr_done = true;
     }
     const int tiles_y = vfi::ceil_div(a.H, T::TH);
     dim3 grid(a.tiles_x * tiles_y, a.Cout_pad / T::BN, N);
-    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, CK, NT>), grid, dim3(256), T::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, CK, NT, UPS>), grid, dim3(256), T::LDS_BYTES, s, a);
     return vfi::check_launch("vfi_conv2d");
 }
 
@@ -298,9 +328,9 @@ extern "C" int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *p
     return vfi::check_launch("vfi_conv2d_pack");
 }
 
-extern "C" int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,
-                          const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
-                          int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream) {
+static int conv2d_impl(const float *x, long long x_bstride, const float *packed_w, const float *bias,
+                       const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
+                       int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, bool ups, vfi_stream_t stream) {
     VFI_REQUIRE(x && packed_w && y, VFI_ERR_INVALID_ARG, "vfi_conv2d: null pointer");
     VFI_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, VFI_ERR_INVALID_ARG, "vfi_conv2d: non-positive size");
     VFI_REQUIRE(KS == 1 || KS == 3 || KS == 5, VFI_ERR_UNSUPPORTED, "vfi_conv2d: kernel size %d", KS);
@@ -318,9 +348,31 @@ extern "C" int vfi_conv2d(const float *x, long long x_bstride, const float *pack
     a.Cin = Cin; a.Cin_pad = round_up(Cin, 8); a.Cout = Cout; a.Cout_pad = round_up(Cout, 32);
     a.H = H; a.W = W; a.tiles_x = vfi::ceil_div(W, 32);
     a.pad_mode = pad_mode; a.act = act;
+    a.Hs = H / 2; a.Ws = W / 2;
+    a.ups_sy = H > 1 ? (float)(a.Hs - 1) / (float)(H - 1) : 0.0f;
+    a.ups_sx = W > 1 ? (float)(a.Ws - 1) / (float)(W - 1) : 0.0f;
     hipStream_t s = vfi::as_stream(stream);
     const bool wide = (a.Cout_pad % 64 == 0);
+    if (ups) {
+        VFI_REQUIRE(KS == 3 && pad_mode == 0 && H % 2 == 0 && W % 2 == 0 && H < 65536 && W < 65536, VFI_ERR_UNSUPPORTED,
+                    "vfi_conv2d_upsample2x: needs KS=3, zero padding, even output size (got KS=%d pad=%d %dx%d)", KS, pad_mode, H, W);
+        return wide ? launch_conv<3, 8, 2, true>(a, N, s) : launch_conv<3, 8, 1, true>(a, N, s);
+    }
     if (KS == 3) return wide ? launch_conv<3, 8, 2>(a, N, s) : launch_conv<3, 8, 1>(a, N, s);
     if (KS == 5) return wide ? launch_conv<5, 4, 2>(a, N, s) : launch_conv<5, 4, 1>(a, N, s);
     return wide ? launch_conv<1, 8, 2>(a, N, s) : launch_conv<1, 8, 1>(a, N, s);
+}
+
+extern "C" int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,
+                          const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
+                          int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream) {
+    return conv2d_impl(x, x_bstride, packed_w, bias, residual, res_bstride, y, y_bstride, N, Cin, H, W, Cout, KS,
+                       pad_mode, act, false, stream);
+}
+
+extern "C" int vfi_conv2d_upsample2x(const float *x_lowres, long long x_bstride, const float *packed_w, const float *bias,
+                                     const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
+                                     int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream) {
+    return conv2d_impl(x_lowres, x_bstride, packed_w, bias, residual, res_bstride, y, y_bstride, N, Cin, H, W, Cout, KS,
+                       pad_mode, act, true, stream);
 }

@@ -81,9 +81,7 @@ class KernelEstimation(PackedModule):
 
     def _up(self, pc, x, skip):
         """Upsample(x2, align_corners=True) -> conv -> ReLU, + skip (fusion_adacofnet.py:28-33,128-146)."""
-        n, c, h, w = x.shape
-        u = ops.resize_bilinear(x, (2 * h, 2 * w), align_corners=True)
-        return ops.conv2d(u, pc, "zeros", "relu", residual=skip)
+        return ops.conv2d(x, pc, "zeros", "relu", residual=skip, upsample2x=True)
 
     def forward_x6(self, x6):
         p = self.packed()
@@ -104,13 +102,13 @@ class KernelEstimation(PackedModule):
             c_mid, c_up, c_out = p[name]
             t = ops.conv2d(h0[:, 64 * i:64 * (i + 1)], c_mid, "zeros", "relu")
             t = ops.conv2d(t, c_up, "zeros", "relu")
-            t = ops.resize_bilinear(t, (2 * h, 2 * w), align_corners=True)
+            # Upsample(x2, align_corners=True) -> conv: one launch, the upsampled tensor is never written
             if name.startswith("moduleWeight"):
-                t = ops.softmax_channels_(ops.conv2d(t, c_out, "zeros", None))
+                t = ops.softmax_channels_(ops.conv2d(t, c_out, "zeros", None, upsample2x=True))
             elif name == "moduleOcclusion":
-                t = ops.conv2d(t, c_out, "zeros", "sigmoid")
+                t = ops.conv2d(t, c_out, "zeros", "sigmoid", upsample2x=True)
             else:
-                t = ops.conv2d(t, c_out, "zeros", None)
+                t = ops.conv2d(t, c_out, "zeros", None, upsample2x=True)
             outs.append(t)
         return tuple(outs)
 

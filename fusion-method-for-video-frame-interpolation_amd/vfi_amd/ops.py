@@ -65,9 +65,13 @@ class PackedConv:
         self._keep = (weight, scale)  # alive until the pack kernel has run (same stream ordering)
 
 
-def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None):
-    """act(conv(x) + bias) (+ residual) -> out.  One vfi_conv2d launch."""
+def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2x=False):
+    """act(conv(x) + bias) (+ residual) -> out.  One vfi_conv2d launch.  upsample2x: x is the low-resolution
+    input of an `Upsample(x2, bilinear, align_corners=True) -> conv` pair (the upsampled tensor is not
+    materialised)."""
     n, cin, h, w = x.shape
+    if upsample2x:
+        h, w = 2 * h, 2 * w
     if cin != pc.cin:
         raise VfiLibraryError(f"conv2d: input has {cin} channels, weights expect {pc.cin}")
     if out is None:
@@ -83,9 +87,10 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None):
         rp, rs = _slice_ptr(residual, "residual")
     work = None
     if _lib.PROFILE is not None:
-        label = f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}>"
+        label = (f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}"
+                 + (",ups>" if upsample2x else ">"))
         work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w, label)
-    _lib.call("vfi_conv2d", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), rp, rs, yp, ys,
+    _lib.call("vfi_conv2d_upsample2x" if upsample2x else "vfi_conv2d", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), rp, rs, yp, ys,
               n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], _lib.stream_ptr(), work=work)
     return out
 

@@ -126,6 +126,14 @@ int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const
                const float *residual, long long res_bstride, float *y, long long y_bstride, int N, int Cin,
                int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream);
 
+/* conv2d( nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)(x_lowres) ) in one launch: the
+ * `Upsample -> Conv2d` pairs of KernelEstimation (src/fusion_net/fusion_adacofnet.py:28-33 and the heads'
+ * tails :41-43,53-56,67-70).  x_lowres is (N, Cin, H/2, W/2); H, W are the OUTPUT size (even); the upsampled
+ * tensor is never written to HBM (the tile loader interpolates it).  KS = 3, zero padding only. */
+int vfi_conv2d_upsample2x(const float *x_lowres, long long x_bstride, const float *packed_w, const float *bias,
+                          const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
+                          int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Glue between the convolutions (HBM-bound; batch strides as for vfi_conv2d)
  * ---------------------------------------------------------------------------------- */

@@ -111,3 +111,19 @@ def test_conv_argument_errors(device):
         ops.conv2d(torch.zeros(1, 4, 8, 8), pc)                         # CPU tensor: no fallback
     with pytest.raises(ops.VfiLibraryError):
         ops.conv2d(torch.zeros(1, 4, 1, 8, device=device), pc, "reflect")  # reflect pad >= size
+
+
+@pytest.mark.parametrize("n,cin,cout,hs,ws,act", [(1, 25, 25, 24, 40, None), (2, 64, 64, 9, 17, "relu"),
+                                                   (1, 64, 1, 16, 16, "sigmoid"), (1, 128, 128, 8, 12, "relu")])
+def test_conv_fused_upsample_matches_torch(n, cin, cout, hs, ws, act, device):
+    # Upsample(x2, bilinear, align_corners=True) -> conv3x3 (+act, +skip) in one launch
+    g = torch.Generator().manual_seed(cin + hs)
+    x = torch.randn((n, cin, hs, ws), generator=g)
+    wgt = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    res = torch.randn((n, cout, 2 * hs, 2 * ws), generator=g)
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = _ref(up, wgt, b, 3, "zeros", act, res=res)
+    pc = ops.PackedConv(wgt, b, device=device)
+    out = ops.conv2d(x.to(device), pc, "zeros", act, residual=res.to(device), upsample2x=True)
+    assert (out.cpu() - ref).abs().max().item() <= 3e-5
