@@ -160,19 +160,107 @@ __global__ __launch_bounds__(256) void median_kernel(const float *__restrict__ x
             kmin = min(kmin, k);
             kmax = max(kmax, k);
         }
-    const int need = (S * S) / 2 + 1;  // smallest key with count(key <= K) >= rank+1
+    const int need = (S * S) / 2 + 1;  // smallest key K with count(key <= K) >= rank+1
+    // Invariants: count(key < lo) = c_lo < need  and  count(key <= hi) = c_hi >= need.  Every second probe is
+    // an interpolation step on the (locally near-linear) rank function, the others plain bisection, so the
+    // search ends in <= 2*32 probes worst case and typically a third of the bisection count.
     unsigned lo = kmin, hi = kmax;
+    int c_lo = 0, c_hi = S * S;
+    int it = 0;
     while (__any(lo < hi)) {
         const bool active = lo < hi;
-        const unsigned mid = lo + (hi - lo) / 2;
+        unsigned mid = lo + (hi - lo) / 2;
+        if ((it & 1) == 0 && active) {
+            const float frac = ((float)(need - c_lo) - 0.5f) / (float)(c_hi - c_lo);
+            const unsigned span = hi - lo;
+            const unsigned g = lo + (unsigned)fminf((float)span * fminf(fmaxf(frac, 0.0f), 1.0f), (float)(span - 1));
+            mid = min(max(g, lo), hi - 1);
+        }
         int cnt = 0;
         for (int r = 0; r < S; ++r)
             for (int c = 0; c < S; ++c) cnt += base[r * PW + c] <= mid ? 1 : 0;
         if (active) {
-            if (cnt >= need) hi = mid; else lo = mid + 1;
+            if (cnt >= need) { hi = mid; c_hi = cnt; } else { lo = mid + 1; c_lo = cnt; }
         }
+        ++it;
     }
     if (gx < W && gy < H) y[(size_t)n * H * W + (size_t)gy * W + gx] = float_of(lo);
+}
+
+// ---- exact median, rank-transform + sliding bitset (the fast path, used whenever the tile fits) -------------------
+// A 16-column x 64-row output tile and its (16+S-1) x (64+S-1) input window (<= 8192 keys):
+//   1. the window's keys are sorted ONCE (bitonic sort of (key, position) pairs in LDS, 256 threads) and every
+//      position is replaced by its rank, a unique integer < 8192;
+//   2. one thread per output row keeps the set of ranks inside its SxS window as a bitset; sliding the window one
+//      column clears S bits and sets S bits (LDS atomics, no return value) and nudges a (word, popcount-below)
+//      cursor to the median rank -- ~2*S LDS operations per output pixel instead of ~20 sweeps of S*S keys;
+//   3. the median is the sorted key at that rank: an element of the window, bit-exact with scipy.
+constexpr int kRkTW = 16, kRkTH = 64, kRkN = 8192, kRkWords = kRkN / 32;
+
+__global__ __launch_bounds__(256) void median_rank_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, int S) {
+    extern __shared__ unsigned smem[];
+    unsigned *K = smem;                                              // [8192] keys, sorted in place
+    unsigned short *I = reinterpret_cast<unsigned short *>(K + kRkN);   // [8192] original position of each sorted key
+    unsigned short *R = I + kRkN;                                    // [8192] rank of each position
+    unsigned *B = reinterpret_cast<unsigned *>(R + kRkN);            // [64][256] one bitset per output row
+    const int PW = kRkTW + S - 1, PH = kRkTH + S - 1, U = PW * PH;
+    const int n = blockIdx.z, x0 = blockIdx.x * kRkTW, y0 = blockIdx.y * kRkTH, lo_off = S / 2;
+    const float *p = x + (size_t)n * H * W;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < kRkN; e += 256) {
+        unsigned k = 0xffffffffu;
+        if (e < U) {
+            const int r = e / PW, c = e % PW;
+            k = key_of(p[(size_t)sym_reflect(y0 - lo_off + r, H) * W + sym_reflect(x0 - lo_off + c, W)]);
+        }
+        K[e] = k;
+        I[e] = (unsigned short)e;
+    }
+    for (int e = tid; e < kRkTH * kRkWords; e += 256) B[e] = 0u;
+    __syncthreads();
+    for (int k = 2; k <= kRkN; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < kRkN / 2; t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const unsigned a = K[i], b = K[l];
+                if ((a > b) == ((i & k) == 0)) {
+                    K[i] = b; K[l] = a;
+                    const unsigned short ia = I[i]; I[i] = I[l]; I[l] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    for (int e = tid; e < kRkN; e += 256) R[I[e]] = (unsigned short)e;   // padding (key 0xffffffff) sorts last: ranks >= U unused
+    __syncthreads();
+    if (tid < kRkTH) {
+        unsigned *bits = B + tid * kRkWords;
+        const unsigned short *rows = R + tid * PW;      // window of output row `tid` starts at union row `tid`
+        const int need = (S * S) / 2 + 1;
+        for (int r = 0; r < S; ++r)
+            for (int c = 0; c < S; ++c) {
+                const unsigned rk = rows[r * PW + c];
+                atomicOr(&bits[rk >> 5], 1u << (rk & 31));
+            }
+        int ptr = 0, below = 0;
+        const int gy = y0 + tid;
+        for (int tx = 0; tx < kRkTW; ++tx) {
+            if (tx > 0) {
+                for (int r = 0; r < S; ++r) {
+                    const unsigned out = rows[r * PW + tx - 1], in = rows[r * PW + tx + S - 1];
+                    atomicAnd(&bits[out >> 5], ~(1u << (out & 31)));
+                    atomicOr(&bits[in >> 5], 1u << (in & 31));
+                    below += ((int)(in >> 5) < ptr) - ((int)(out >> 5) < ptr);
+                }
+            }
+            while (below >= need) { --ptr; below -= __popc(bits[ptr]); }
+            unsigned wv = bits[ptr];
+            while (below + __popc(wv) < need) { below += __popc(wv); wv = bits[++ptr]; }
+            for (int i = need - below; i > 1; --i) wv &= wv - 1;      // drop the (need-below-1) lowest set bits
+            const int rank = ptr * 32 + __ffs(wv) - 1;
+            const int gx = x0 + tx;
+            if (gx < W && gy < H) y[(size_t)n * H * W + (size_t)gy * W + gx] = float_of(K[rank]);
+        }
+    }
 }
 
 }  // namespace
@@ -230,6 +318,19 @@ extern "C" int vfi_median_filter(const float *x, float *y, int N, int H, int W, 
     VFI_REQUIRE(N > 0 && H > 0 && W > 0 && size >= 1, VFI_ERR_INVALID_ARG, "vfi_median_filter: bad arguments");
     VFI_REQUIRE(size <= 64, VFI_ERR_UNSUPPORTED, "vfi_median_filter: size %d > 64", size);
     VFI_REQUIRE(N <= 65535, VFI_ERR_UNSUPPORTED, "vfi_median_filter: batch");
+    if ((kRkTW + size - 1) * (kRkTH + size - 1) <= kRkN && size >= 2) {
+        constexpr size_t lds = kRkN * 4 + kRkN * 2 * 2 + (size_t)kRkTH * kRkWords * 4;   // 128 KiB
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(median_rank_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return vfi::fail(VFI_ERR_LAUNCH, "vfi_median_filter: set LDS size: %s", hipGetErrorString(e));
+            attr_done = true;
+        }
+        dim3 grid(ceil_div(W, kRkTW), ceil_div(H, kRkTH), N);
+        hipLaunchKernelGGL(median_rank_kernel, grid, dim3(256), lds, vfi::as_stream(stream), x, y, H, W, size);
+        return vfi::check_launch("vfi_median_filter");
+    }
     const size_t lds = (size_t)(kMedTW + size - 1) * (kMedTH + size - 1) * sizeof(unsigned);
     dim3 grid(ceil_div(W, kMedTW), ceil_div(H, kMedTH), N);
     hipLaunchKernelGGL(median_kernel, grid, dim3(256), lds, vfi::as_stream(stream), x, y, H, W, size);

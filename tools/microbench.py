@@ -56,6 +56,15 @@ def main():
     dev = torch.device("cuda:0")
     if args.what == "adacof":
         bench_adacof(dev)
+    if args.what == "median":
+        import numpy as np
+        h, w = 1080, 1920
+        yy, xx = np.meshgrid(np.linspace(0, 6, h), np.linspace(0, 9, w), indexing="ij")
+        smooth = torch.from_numpy((np.sin(yy) * np.cos(xx) + 0.1 * np.sin(7 * xx)).astype(np.float32)[None]).to(dev)
+        noise = torch.randn((1, h, w), device=dev)
+        for name, x in (("smooth", smooth), ("noise", noise)):
+            t = timeit(lambda: ops.median_filter(x, 50), iters=5, warm=1)
+            print(f"median50 1080p {name}: {t*1e3:.3f} ms", flush=True)
     if args.what == "conv":
         tot_f, tot_t = 0.0, 0.0
         for name, n, cin, cout, h, w, ks, pad in conv_cases():
