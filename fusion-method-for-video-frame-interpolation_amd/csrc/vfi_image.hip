@@ -81,9 +81,9 @@ __global__ void channel_mean_diff_kernel(const float *__restrict__ a, const floa
             if (b) sb += b[((size_t)n * C + c) * HW + p];
         }
         float v = sa / (float)C;
-        if (b) v = fabsf(v - sb / (float)C);
+        if (b) { v = v - sb / (float)C; if (!(clamp01 & 2)) v = fabsf(v); }
         v *= scale;
-        out[i] = clamp01 ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
+        out[i] = (clamp01 & 1) ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
     }
 }
 // out = |x - y| * scale, optionally clamped   (subtract_values: src/train/utils.py:322-346; :223-224)

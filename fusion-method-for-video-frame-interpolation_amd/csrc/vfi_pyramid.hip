@@ -60,6 +60,9 @@ struct vfi_pyr_plan {
     std::map<std::pair<int, int>, hipfftHandle> c2c;  // (level or -1 = low, -2 = full; batch)
     std::map<int, hipfftHandle> r2c, c2r;
     std::vector<void *> allocs;
+    // kept for vfi_pyr_plan_prepare_filter
+    std::vector<double> log_rad, xr0, yr, yir;
+    std::vector<float *> filters;   // [id] -> H x (W/2+1) radial gain tables
 };
 
 namespace {
@@ -152,6 +155,7 @@ int build_tables(vfi_pyr_plan *p) {
         ys[i] = std::sqrt(cst) * c;
     }
     std::vector<double> xcb(nl);
+    p->log_rad = log_rad; p->xr0 = xr; p->yr = yr; p->yir = yir;
 
     std::vector<float> t((size_t)H * W), t2((size_t)H * W);
     for (int u = 0; u < H; ++u)
@@ -364,6 +368,17 @@ __global__ __launch_bounds__(256) void pyr_final_kernel(float2 *__restrict__ cur
     }
 }
 
+// half spectrum *= gain (already includes 1/(H*W) for the un-normalised C2R)
+__global__ void pyr_gain_kernel(float2 *__restrict__ half, const float *__restrict__ gain, int N, long long per_image) {
+    const long long total = (long long)N * per_image;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float g = gain[i % per_image];
+        float2 z = half[i];
+        z.x *= g; z.y *= g;
+        half[i] = z;
+    }
+}
+
 // ---- FFT plan cache ---------------------------------------------------------------------------------------
 int get_c2c(vfi_pyr_plan *p, int key, int h, int w, int batch, hipfftHandle *out) {
     auto it = p->c2c.find({key, batch});
@@ -445,6 +460,59 @@ extern "C" int vfi_pyr_plan_create(int H, int W, int height, int nbands, double 
     }
     *out = p;
     return VFI_OK;
+}
+
+extern "C" int vfi_pyr_plan_prepare_filter(vfi_pyr_plan *p, unsigned long long level_mask, int keep_high, int keep_low,
+                                           int *filter_id) {
+    VFI_REQUIRE(p && filter_id, VFI_ERR_INVALID_ARG, "vfi_pyr_plan_prepare_filter: null pointer");
+    const int H = p->H, W = p->W, wh = W / 2 + 1;
+    const double ls = std::log2(p->scale);
+    std::vector<float> g((size_t)H * wh);
+    for (int u = 0; u < H; ++u)
+        for (int v = 0; v < wh; ++v) {
+            const int fy = u <= H - H / 2 - 1 ? u : u - H, fx = v;          // signed frequencies (v < wh: non-negative)
+            const double lr = p->log_rad[(size_t)shifted_of(u, H) * W + shifted_of(v, W)];
+            const double lo0 = interp(lr, p->xr0, p->yir), hi0 = interp(lr, p->xr0, p->yr);
+            double lowchain = 1.0, acc = 0.0;       // prod_{j<k} lomask_j^2 on the running window
+            std::vector<double> xr = p->xr0;
+            for (int k = 0; k <= p->nlev; ++k) {
+                const int h = k < p->nlev ? p->lev[k].h : p->hl, w = k < p->nlev ? p->lev[k].w : p->wl;
+                const bool inside = fy >= -(h / 2) && fy <= h - h / 2 - 1 && fx >= -(w / 2) && fx <= w - w / 2 - 1;
+                if (!inside) { lowchain = 0.0; break; }
+                if (k == p->nlev) break;
+                for (auto &x : xr) x -= ls;
+                const double hm = interp(lr, xr, p->yr), lm = interp(lr, xr, p->yir);
+                if ((level_mask >> k) & 1ull) acc += lowchain * hm * hm;
+                lowchain *= lm * lm;
+            }
+            if (keep_low) acc += lowchain;
+            const double gain = (keep_high ? hi0 * hi0 : 0.0) + lo0 * lo0 * acc;
+            g[(size_t)u * wh + v] = (float)(gain / ((double)H * W));
+        }
+    float *dev = nullptr;
+    int rc = dev_upload(p, g, &dev);
+    if (rc) return vfi::fail(rc, "vfi_pyr_plan_prepare_filter: device allocation / upload failed");
+    p->filters.push_back(dev);
+    *filter_id = (int)p->filters.size() - 1;
+    return VFI_OK;
+}
+
+extern "C" int vfi_pyr_apply_filter(vfi_pyr_plan *p, int filter_id, const float *img, int N, float *out, vfi_stream_t stream) {
+    VFI_REQUIRE(p && img && out, VFI_ERR_INVALID_ARG, "vfi_pyr_apply_filter: null pointer");
+    VFI_REQUIRE(filter_id >= 0 && filter_id < (int)p->filters.size(), VFI_ERR_INVALID_ARG, "vfi_pyr_apply_filter: bad filter id %d", filter_id);
+    VFI_REQUIRE(N >= 1 && N <= p->max_images, VFI_ERR_INVALID_ARG, "vfi_pyr_apply_filter: N=%d (plan max %d)", N, p->max_images);
+    hipStream_t s = vfi::as_stream(stream);
+    hipfftHandle f;
+    int rc;
+    if ((rc = get_real(p, true, N, &f))) return rc;
+    FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_apply_filter");
+    FFT_CHECK(hipfftExecR2C(f, const_cast<float *>(img), reinterpret_cast<hipfftComplex *>(p->half0)), "vfi_pyr_apply_filter R2C");
+    const long long per = (long long)p->H * (p->W / 2 + 1);
+    hipLaunchKernelGGL(pyr_gain_kernel, dim3(blocks_1d(per * N)), dim3(256), 0, s, p->half0, p->filters[filter_id], N, per);
+    if ((rc = get_real(p, false, N, &f))) return rc;
+    FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_apply_filter");
+    FFT_CHECK(hipfftExecC2R(f, reinterpret_cast<hipfftComplex *>(p->half0), out), "vfi_pyr_apply_filter C2R");
+    return vfi::check_launch("vfi_pyr_apply_filter");
 }
 
 extern "C" int vfi_pyr_plan_destroy(vfi_pyr_plan *p) {

@@ -90,14 +90,18 @@ class FusionInterpolator:
         lab_pred = pyr.inv_filter(DecompValues(0, vals_pred.phase, vals_pred.amplitude, vals_pred.low_level))
         phase_pred = ops.lab2rgb(lab_pred)                                             # (3,H,W) rgb
 
-        # uncertainty maps (:198-225): only the finest and the 6 coarsest band levels are ever used
+        # uncertainty maps (:198-225)
         coarse = min(6, nlev)
-        mask = 1 | (((1 << coarse) - 1) << (nlev - coarse))
-        vb = pyr.filter(torch.cat((ada_pred[0], phase_pred), 0), level_mask=mask)      # 6 images, RGB space
-        fine = DecompValues(vb.high_level, [vb.phase[0]] + [0] * (nlev - 1), [vb.amplitude[0]] + [0] * (nlev - 1), 0)
-        hf = pyr.inv_filter(fine)                                                      # (6,H,W): ada | phase
-        d = ops.channel_mean_diff(hf[:3].unsqueeze(0), hf[3:].unsqueeze(0), 100.0, True)   # :207-211
+        # phase uncertainty (:205-214): h_freq - h_freq_ph = G * (mean_c(ada_pred) - mean_c(rgb_pred)) with G the radial
+        # gain of "finest band level + high residual" -- both get_last_value_levels reconstructions are linear in
+        # unmodified values, so 48 band FFTs collapse into one R2C / C2R pair on one image
+        m = ops.channel_mean_diff(ada_pred, phase_pred.unsqueeze(0), 1.0, False, signed=True)      # (1,H,W)
+        hf = pyr.band_filter(m, level_mask=1, keep_high=True)
+        d = ops.absdiff(hf, torch.zeros_like(hf), 100.0, True)                          # :210-211
         phase_uncertainty = ops.gaussian_filter(d, 5)                                  # :212-214  (1,H,W)
+        # ada uncertainty (:217-225): |phase|,|amp| differences are not linear -> transform the 6 coarsest levels
+        mask = ((1 << coarse) - 1) << (nlev - coarse)
+        vb = pyr.filter(torch.cat((ada_pred[0], phase_pred), 0), level_mask=mask, want_high=False)   # 6 images, RGB space
         half = lambda t: (t[:12], t[12:])                                              # ada planes | phase planes
         dp, da = [0] * nlev, [0] * nlev
         for k in range(nlev - coarse, nlev):
@@ -116,9 +120,10 @@ class FusionInterpolator:
         out = {"phase_pred": pp, "ada_pred": ada_pred, "base": base, "flow_var_map": flow_var_map,
                "phase_uncertainty": phase_uncertainty, "ada_uncertainty": ada_uncertainty}
         if output_baseline:                                                            # :288-322
-            va = pyr.filter(ops.rgb2lab(ada_pred[0]))
-            vp = pyr.filter(ops.rgb2lab(phase_pred))
             split = nlev // 2
+            # only the parts that survive the mix are transformed (level masks)
+            va = pyr.filter(ops.rgb2lab(ada_pred[0]), level_mask=((1 << nlev) - 1) & ~((1 << split) - 1), want_low=False)
+            vp = pyr.filter(ops.rgb2lab(phase_pred), level_mask=(1 << split) - 1, want_high=False)
             mix = DecompValues(va.high_level, vp.phase[:split] + va.phase[split:],
                                vp.amplitude[:split] + va.amplitude[split:], vp.low_level)
             out["baseline"] = ops.lab2rgb(pyr.inv_filter(mix)).unsqueeze(0)

@@ -186,13 +186,13 @@ def lab2rgb(lab):
     return out
 
 
-def channel_mean_diff(a, b=None, scale=1.0, clamp01=False):
-    """a, b (N,C,H,W) -> (N,H,W): mean over C of a (minus that of b, abs), * scale, optional clamp."""
+def channel_mean_diff(a, b=None, scale=1.0, clamp01=False, signed=False):
+    """a, b (N,C,H,W) -> (N,H,W): mean over C of a (minus that of b; abs unless signed), * scale, optional clamp."""
     a = a.contiguous()
     n, c, h, w = a.shape
     out = torch.empty((n, h, w), dtype=torch.float32, device=a.device)
     _lib.call("vfi_channel_mean_diff", _lib.dptr(a, "a"), _lib.dptr(b.contiguous(), "b") if b is not None else None,
-              out.data_ptr(), n, c, h * w, float(scale), int(bool(clamp01)), _lib.stream_ptr())
+              out.data_ptr(), n, c, h * w, float(scale), int(bool(clamp01)) | (2 if signed else 0), _lib.stream_ptr())
     return out
 
 

@@ -62,6 +62,21 @@ class Plan:
                   low.data_ptr() if torch.is_tensor(low) else None, float(phase_scale), mask, flags, _lib.stream_ptr(),
                   work=("byte", self._bytes(n, mask, torch.is_tensor(high), torch.is_tensor(low)), "pyr_analyze"))
 
+    def band_filter(self, img, level_mask, keep_high, keep_low):
+        """real(ifft2(fft2(img) * G)): analysis + synthesis of an unmodified level subset as ONE radial filter."""
+        key = (int(level_mask), bool(keep_high), bool(keep_low))
+        if not hasattr(self, "_filters"):
+            self._filters = {}
+        if key not in self._filters:
+            fid = ctypes.c_int()
+            _lib.call("vfi_pyr_plan_prepare_filter", self._h, key[0], int(key[1]), int(key[2]), ctypes.byref(fid))
+            self._filters[key] = fid.value
+        out = torch.empty_like(img)
+        n = img.shape[0]
+        _lib.call("vfi_pyr_apply_filter", self._h, self._filters[key], _lib.dptr(img, "img"), n, out.data_ptr(),
+                  _lib.stream_ptr(), work=("byte", 8.0 * n * self.h * self.w, "pyr_band_filter"))
+        return out
+
     def synthesize(self, high, phase, amp, table, low, mask, flags, img):
         n = img.shape[0]
         tab = (ctypes.c_int * len(table))(*table) if table is not None else None

@@ -95,6 +95,14 @@ class Pyramid:
         out = DecompValues(high, phase[::-1], amp[::-1], low)
         return out, bufs[::-1]
 
+    def band_filter(self, img, level_mask, keep_high=False, keep_low=False):
+        """== inv_filter(keep(filter(img))) where `keep` zeroes every band level not in level_mask and the
+        high / low residuals unless kept (get_last_value_levels / get_first_value_levels applied to UNMODIFIED
+        values): a single radial frequency-domain gain (see vfi_pyr_plan_prepare_filter).  img (N,H,W)."""
+        img = img.contiguous()
+        n, h, w = img.shape
+        return self.pyr.plan(h, w, n).band_filter(img, level_mask, keep_high, keep_low)
+
     # -- synthesis -------------------------------------------------------------------------------------
     def inv_filter(self, vals):
         """Psi^{-1} filter: per-image DecompValues -> (N,H,W)."""

@@ -211,6 +211,18 @@ int vfi_pyr_plan_destroy(vfi_pyr_plan *plan);
  * ceil(H / scale_factor^level) x ceil(W / scale_factor^level). */
 int vfi_pyr_plan_level_size(const vfi_pyr_plan *plan, int level, int *h, int *w);
 
+/* Analysis followed by synthesis of an UNMODIFIED subset of the pyramid is a real, radially symmetric linear
+ * filter (the four orientation masks form a partition of unity):
+ *   inv_filter(keep(filter(x))) = real(ifft2(fft2(x) * G)),
+ *   G = [keep_high] hi0^2 + lo0^2 * ( sum_{k in level_mask} (prod_{j<k} lomask_j^2) himask_k^2 + [keep_low] prod_j lomask_j^2 ).
+ * vfi_pyr_plan_prepare_filter builds G once (allocates; returns an id), vfi_pyr_apply_filter applies it to
+ * N images (N,H,W) with one R2C, one multiply and one C2R.  Replaces
+ * `pyr.inv_filter(get_last_value_levels(vals, 1))` of src/fusion_net/interpolate_twoframe.py:205-209
+ * (24 band FFTs forward and back per call) wherever the kept values are not modified in between. */
+int vfi_pyr_plan_prepare_filter(vfi_pyr_plan *plan, unsigned long long level_mask, int keep_high, int keep_low,
+                                int *filter_id);
+int vfi_pyr_apply_filter(vfi_pyr_plan *plan, int filter_id, const float *img, int N, float *out, vfi_stream_t stream);
+
 /* Pyramid.filter = SCFpyr_PyTorch.build + coeff_to_values (src/train/pyramid.py:35-39,48-78).
  *   img    (N, H, W)
  *   high   (N, H, W) or NULL;  low (N, hL, wL) or NULL
@@ -244,7 +256,8 @@ int vfi_pyr_synthesize(vfi_pyr_plan *plan, const float *high, const float *const
 int vfi_rgb2lab(const float *rgb, float *lab, int N, int HW, vfi_stream_t stream);
 int vfi_lab2rgb(const float *lab, float *rgb, int N, int HW, vfi_stream_t stream);
 
-/* out (N,HW) = mean_c a  (b == NULL)   or   |mean_c a - mean_c b|,  times scale, clamped to [0,1] if clamp01
+/* out (N,HW) = mean_c a  (b == NULL)   or   |mean_c a - mean_c b|,  times scale; clamp01 is a flag word:
+ * bit 0 clamps to [0,1], bit 1 keeps the SIGNED difference (no abs)
  * (src/fusion_net/interpolate_twoframe.py:207-211,219-220: `.mean(1)`, abs, `*100`/`*30`, clamp). */
 int vfi_channel_mean_diff(const float *a, const float *b, float *out, int N, int C, int HW, float scale,
                           int clamp01, vfi_stream_t stream);

@@ -144,3 +144,22 @@ def test_full_size_1080p_properties(device):
     vals2 = pyr.filter(0.5 * img)
     y2 = pyr.inv_filter(sub(vals2))
     assert (y1 * 0.5 - y2).abs().max().item() <= 2e-5
+
+
+def test_band_filter_equals_analysis_plus_masked_synthesis(device):
+    # inv_filter(get_last_value_levels(filter(x), 1)) == one radial gain (partition of unity of the 4 orientations)
+    h, w = 90, 120
+    height = layout_cpu.calc_pyr_height(h, w)
+    img = _images(6, 1, h, w)[:3]
+    opyr = pyramid_cpu.Pyramid(height)
+    ref = opyr.inv_filter(layout_cpu.get_last_value_levels(opyr.filter(img), 1))
+    ref2 = opyr.inv_filter(layout_cpu.get_first_value_levels(opyr.filter(img), 3))
+    pyr = Pyramid(height, 4, S2, device)
+    got = pyr.band_filter(img.to(device), level_mask=1, keep_high=True).cpu()
+    assert (got - ref).abs().max().item() <= 2e-5
+    nlev = height - 2
+    got2 = pyr.band_filter(img.to(device), level_mask=0b111 << (nlev - 3), keep_low=True).cpu()
+    assert (got2 - ref2).abs().max().item() <= 2e-5
+    # all levels + both residuals == identity
+    full = pyr.band_filter(img.to(device), level_mask=(1 << nlev) - 1, keep_high=True, keep_low=True).cpu()
+    assert (full - img).abs().max().item() <= 2e-5
