@@ -149,21 +149,37 @@ def main():
                            "sharding": f"frame pairs over {world} rank(s), no data-path collective",
                            "frames_in_flight_per_gpu": args.streams}}
         if not args.no_profile:
-            # one extra, event-timed frame: per-kernel algorithmic work / measured duration on the launch stream
-            torch.cuda.synchronize()
-            _lib.PROFILE = _lib.Recorder()
-            f0, f2 = pairs[0]
-            runners[0](f0, f2, output_baseline=True)          # one frame alone on the default stream
-            agg = _lib.PROFILE.summary()
-            _lib.PROFILE = None
-            convs = {k: v for k, v in agg.items() if v["kind"] == "flop"}
-            dom = max(convs, key=lambda k: convs[k]["seconds"])
-            d = convs[dom]
-            tf = d["work"] / d["seconds"] / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
-                                "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                                "launches_per_frame": d["calls"], "avg_launch_ms": d["seconds"] / d["calls"] * 1e3,
-                                "frame_share": d["seconds"] / sum(v["seconds"] for v in agg.values())}
+            # Per-kernel algorithmic work / measured duration (HIP events on the launch stream of each call).
+            #  * "roofline": measured in the SAME regime as the timed region (one frame per stream, S frames in
+            #    flight), so its average launch duration is the one rocprofv3 --stats reports for this command;
+            #  * "roofline_isolated": one frame alone on the device (kernel quality without sharing the chip).
+            def profile(n_frames):
+                torch.cuda.synchronize()
+                _lib.PROFILE = _lib.Recorder()
+                for i in range(n_frames):
+                    step(i)
+                agg = _lib.PROFILE.summary()
+                _lib.PROFILE = None
+                return agg
+
+            def roof(agg):
+                convs = {k: v for k, v in agg.items() if v["kind"] == "flop"}
+                dom = max(convs, key=lambda k: convs[k]["seconds"])
+                d = convs[dom]
+                tf = d["work"] / d["seconds"] / 1e12
+                return {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "launches": d["calls"], "avg_launch_ms": d["seconds"] / d["calls"] * 1e3,
+                        "share_of_kernel_time": d["seconds"] / sum(v["seconds"] for v in agg.values())}
+
+            agg = profile(len(runners))
+            line["roofline"] = roof(agg)
+            if len(runners) > 1:
+                saved, runners[:] = list(runners), runners[:1]
+                agg = profile(1)
+                runners[:] = saved
+                line["roofline_isolated"] = roof(agg)
+            dom = line["roofline"]["kernel"]
             line["roofline_other"] = []
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"]):
                 if k == dom or not v["kind"]:
@@ -173,7 +189,7 @@ def main():
                 line["roofline_other"].append({"kernel": k, "bound": "mfma" if v["kind"] == "flop" else "hbm",
                                                "achieved": rate / div, "peak": peak, "unit": unit, "frac": rate / div / peak,
                                                "calls": v["calls"], "ms_per_frame": v["seconds"] * 1e3})
-            line["stage_ms"] = {k: round(v["seconds"] * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"])[:12]}
+            line["stage_ms_isolated"] = {k: round(v["seconds"] * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"])[:14]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     if world > 1:
