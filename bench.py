@@ -71,7 +71,7 @@ def build_runner(device, n_streams=1, seed=0):
     return [FusionInterpolator(adacof, fusion, state, device) for _ in range(n_streams)], n
 
 
-def cpu_baseline(sample_hw=(272, 480), full_hw=(1080, 1920), threads=16):
+def cpu_baseline(sample_hw=(544, 960), full_hw=(1080, 1920), threads=16):
     """The oracle pipeline (CPU restatement of the same path) on a bounded sample, scaled by pixel count."""
     from oracle import pipeline_cpu, synth
     threads = max(1, min(threads, os.cpu_count() or 1))
