@@ -158,7 +158,9 @@ struct FlowStats {  // pivoted weighted moments of one offset plane (alpha or be
     float m, q;
 };
 
-template <int C, int VEC, int FT, int UNROLL_L, int MIN_WAVES, bool RGBX = false>
+// SOFTMAX: w1/w2 hold the LOGITS of Subnet_weight (fusion_adacofnet.py:46-57); the softmax over the F*F taps is
+// folded into the accumulation (online max rescaling), so the normalised weights are never written to HBM.
+template <int C, int VEC, int FT, int UNROLL_L, int MIN_WAVES, bool RGBX = false, bool SOFTMAX = false>
 __global__ __launch_bounds__(256, MIN_WAVES) void adacof_fused_kernel(
     const float *__restrict__ frame0, const float *__restrict__ frame2,
     const float *__restrict__ w1, const float *__restrict__ a1, const float *__restrict__ b1,
@@ -183,13 +185,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void adacof_fused_kernel(
         const float *__restrict__ wp = side ? w2 : w1;
         const float *__restrict__ ap = side ? a2 : a1;
         const float *__restrict__ bp = side ? b2 : b1;
-        float s[VEC], pa[VEC], pb[VEC];
+        float s[VEC], pa[VEC], pb[VEC], mx[VEC];
         FlowStats sa[VEC], sb[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
 #pragma unroll
             for (int c = 0; c < C; ++c) res[side][v][c] = 0.0f;
             s[v] = 0.0f;
+            mx[v] = -INFINITY;
             sa[v] = {0.0f, 0.0f};
             sb[v] = {0.0f, 0.0f};
         }
@@ -213,6 +216,16 @@ __global__ __launch_bounds__(256, MIN_WAVES) void adacof_fused_kernel(
                 b.load(bp + t);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
+                    if constexpr (SOFTMAX) {   // w = exp(logit - running max); rescale what was accumulated so far
+                        const float mnew = fmaxf(mx[v], w.v[v]);
+                        const float sc = expf(mx[v] - mnew);
+                        w.v[v] = expf(w.v[v] - mnew);
+                        mx[v] = mnew;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) res[side][v][c] *= sc;
+                        s[v] *= sc;
+                        sa[v].m *= sc; sa[v].q *= sc; sb[v].m *= sc; sb[v].q *= sc;
+                    }
                     if constexpr (RGBX)
                         tap_accumulate_rgbx(reinterpret_cast<const float4 *>(in), H, W, y + k * dil - pad,
                                             x0 + v + l * dil - pad, w.v[v], a.v[v], b.v[v], res[side][v]);
@@ -233,6 +246,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void adacof_fused_kernel(
         //   Var = M'^2 (S - 2) + Q' + 2 c M' (S - 1) + c^2 S
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
+            if constexpr (SOFTMAX) {   // normalise: every accumulated sum is linear in the weights
+                const float inv = 1.0f / s[v];
+#pragma unroll
+                for (int c = 0; c < C; ++c) res[side][v][c] *= inv;
+                sa[v].m *= inv; sa[v].q *= inv; sb[v].m *= inv; sb[v].q *= inv;
+                s[v] = 1.0f;
+            }
             const float S = s[v];
             const float ca = pa[v] * (S - 1.0f), cb = pb[v] * (S - 1.0f);
             const float va = sa[v].m * sa[v].m * (S - 2.0f) + sa[v].q + 2.0f * ca * sa[v].m * (S - 1.0f) + ca * ca * S;
@@ -305,7 +325,7 @@ static int adacof_fused_impl(const float *frame0, const float *frame2, const flo
                              const float *a1, const float *b1, const float *w2, const float *a2,
                              const float *b2, const float *occ, float *out_t1, float *out_t2,
                              float *out_frame, float *out_mask, int N, int C, int H, int W, int F,
-                             int dilation, bool rgbx, vfi_stream_t stream) {
+                             int dilation, bool rgbx, bool softmax, vfi_stream_t stream) {
     VFI_REQUIRE(frame0 && frame2 && w1 && a1 && b1 && w2 && a2 && b2 && occ && out_frame,
                 VFI_ERR_INVALID_ARG, "vfi_adacof_fused: null pointer");
     VFI_REQUIRE(N > 0 && H > 0 && W > 0 && F > 0 && dilation > 0, VFI_ERR_INVALID_ARG,
@@ -333,8 +353,15 @@ static int adacof_fused_impl(const float *frame0, const float *frame2, const flo
 #define LAUNCH(VEC, FT, UN, MW)                                                                          \
     hipLaunchKernelGGL((adacof_fused_kernel<3, VEC, FT, UN, MW>), grid, block, 0, s, frame0, frame2, w1, a1, b1, \
                        w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, H, W, F, dilation)
+    if (softmax) VFI_REQUIRE(rgbx, VFI_ERR_UNSUPPORTED, "vfi_adacof_fused: softmax folding needs the rgbx entry point");
     if (rgbx) {
-        if (F == 5)
+        if (F == 5 && softmax)
+            hipLaunchKernelGGL((adacof_fused_kernel<3, 1, 5, 5, 3, true, true>), grid, block, 0, s, frame0, frame2, w1, a1, b1,
+                               w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, H, W, F, dilation);
+        else if (softmax)
+            hipLaunchKernelGGL((adacof_fused_kernel<3, 1, 0, 1, 4, true, true>), grid, block, 0, s, frame0, frame2, w1, a1, b1,
+                               w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, H, W, F, dilation);
+        else if (F == 5)
             hipLaunchKernelGGL((adacof_fused_kernel<3, 1, 5, 5, 3, true>), grid, block, 0, s, frame0, frame2, w1, a1, b1,
                                w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, H, W, F, dilation);
         else
@@ -357,14 +384,14 @@ extern "C" int vfi_adacof_fused(const float *frame0, const float *frame2, const 
                                 float *out_frame, float *out_mask, int N, int C, int H, int W, int F,
                                 int dilation, vfi_stream_t stream) {
     return adacof_fused_impl(frame0, frame2, w1, a1, b1, w2, a2, b2, occ, out_t1, out_t2, out_frame, out_mask, N, C,
-                             H, W, F, dilation, false, stream);
+                             H, W, F, dilation, false, false, stream);
 }
 
 extern "C" int vfi_adacof_fused_rgbx(const float *frame0_rgbx, const float *frame2_rgbx, const float *w1,
                                      const float *a1, const float *b1, const float *w2, const float *a2,
                                      const float *b2, const float *occ, float *out_t1, float *out_t2,
                                      float *out_frame, float *out_mask, int N, int H, int W, int F,
-                                     int dilation, vfi_stream_t stream) {
+                                     int dilation, int weights_are_logits, vfi_stream_t stream) {
     return adacof_fused_impl(frame0_rgbx, frame2_rgbx, w1, a1, b1, w2, a2, b2, occ, out_t1, out_t2, out_frame,
-                             out_mask, N, 3, H, W, F, dilation, true, stream);
+                             out_mask, N, 3, H, W, F, dilation, true, weights_are_logits != 0, stream);
 }

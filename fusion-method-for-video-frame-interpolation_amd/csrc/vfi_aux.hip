@@ -96,6 +96,42 @@ __global__ void resize_bilinear_kernel(const float *__restrict__ x, long long x_
     }
 }
 
+// 4 consecutive outputs per thread (16-B store / residual load): used when Wout % 4 == 0 and pointers allow
+__global__ void resize_bilinear_vec4_kernel(const float *__restrict__ x, long long x_bs, const float *__restrict__ res,
+                                            long long res_bs, float *__restrict__ y, long long y_bs, int N, int C,
+                                            int Hi, int Wi, int Ho, int Wo, int align_corners, int relu_in) {
+    const float sy = align_corners ? (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f) : (float)Hi / (float)Ho;
+    const float sx = align_corners ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f) : (float)Wi / (float)Wo;
+    const int Wq = Wo / 4;
+    const long long total = (long long)N * C * Ho * Wq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int xq = i % Wq, yo = (i / Wq) % Ho, c = (i / ((long long)Wq * Ho)) % C, n = i / ((long long)Wq * Ho * C);
+        const float fy = align_corners ? sy * yo : fmaxf(sy * (yo + 0.5f) - 0.5f, 0.0f);
+        const int y0 = min((int)fy, Hi - 1), y1 = min(y0 + 1, Hi - 1);
+        const float ly = fy - (float)y0;
+        const float *p0 = x + (size_t)n * x_bs + ((size_t)c * Hi + y0) * Wi;
+        const float *p1 = x + (size_t)n * x_bs + ((size_t)c * Hi + y1) * Wi;
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xo = xq * 4 + k;
+            const float fx = align_corners ? sx * xo : fmaxf(sx * (xo + 0.5f) - 0.5f, 0.0f);
+            const int x0 = min((int)fx, Wi - 1), x1 = min(x0 + 1, Wi - 1);
+            const float lx = fx - (float)x0;
+            float v00 = p0[x0], v01 = p0[x1], v10 = p1[x0], v11 = p1[x1];
+            if (relu_in) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+            out[k] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+        }
+        const size_t o = ((size_t)c * Ho + yo) * Wo + (size_t)xq * 4;
+        float4 v = make_float4(out[0], out[1], out[2], out[3]);
+        if (res) {
+            const float4 r = *reinterpret_cast<const float4 *>(res + (size_t)n * res_bs + o);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4 *>(y + (size_t)n * y_bs + o) = v;
+    }
+}
+
 // ---- softmax over the channel axis (Subnet_weight: fusion_adacofnet.py:56) -----------------------------
 __global__ void softmax_channels_kernel(const float *__restrict__ x, long long x_bs, float *__restrict__ y,
                                         long long y_bs, int N, int C, int HW) {
@@ -233,8 +269,14 @@ extern "C" int vfi_resize_bilinear(const float *x, long long x_bstride, const fl
     VFI_REQUIRE(x && y, VFI_ERR_INVALID_ARG, "vfi_resize_bilinear: null pointer");
     VFI_REQUIRE(N > 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, VFI_ERR_INVALID_ARG,
                 "vfi_resize_bilinear: bad sizes");
-    LAUNCH_1D(resize_bilinear_kernel, (long long)N * C * Hout * Wout, stream, x, x_bstride, residual, res_bstride, y,
-              y_bstride, N, C, Hin, Win, Hout, Wout, align_corners, relu_input);
+    const bool vec = Wout % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0 && y_bstride % 4 == 0 &&
+                     (!residual || ((reinterpret_cast<uintptr_t>(residual) & 15u) == 0 && res_bstride % 4 == 0));
+    if (vec)
+        LAUNCH_1D(resize_bilinear_vec4_kernel, (long long)N * C * Hout * (Wout / 4), stream, x, x_bstride, residual,
+                  res_bstride, y, y_bstride, N, C, Hin, Win, Hout, Wout, align_corners, relu_input);
+    else
+        LAUNCH_1D(resize_bilinear_kernel, (long long)N * C * Hout * Wout, stream, x, x_bstride, residual, res_bstride, y,
+                  y_bstride, N, C, Hin, Win, Hout, Wout, align_corners, relu_input);
     return vfi::check_launch("vfi_resize_bilinear");
 }
 

@@ -40,7 +40,7 @@ class FunctionAdaCoF(torch.autograd.Function):
 
 
 def adacof_fused(frame0, frame2, w1, a1, b1, w2, a2, b2, occ, dilation,
-                 want_sides=True, want_mask=True, rgbx=False):
+                 want_sides=True, want_mask=True, rgbx=False, weights_are_logits=False):
     """Both sampling sides + occlusion blend + flow-variance mask in one launch
     (reference src/fusion_net/fusion_adacofnet.py:195-213).  Frames are UN-padded: planar (N,3,H,W), or
     pixel-interleaved (N,H,W,4) with rgbx=True (as ops.adacof_prepare writes them)."""
@@ -57,9 +57,12 @@ def adacof_fused(frame0, frame2, w1, a1, b1, w2, a2, b2, occ, dilation,
     d = _lib.dptr
     head = ("vfi_adacof_fused_rgbx",) if rgbx else ("vfi_adacof_fused",)
     dims = (n, h, w) if rgbx else (n, c, h, w)
+    if weights_are_logits and not rgbx:
+        raise _lib.VfiLibraryError("weights_are_logits needs rgbx frames")
+    extra = (int(bool(weights_are_logits)),) if rgbx else ()
     _lib.call(*head, d(frame0, "frame0"), d(frame2, "frame2"), d(w1), d(a1), d(b1),
               d(w2), d(a2), d(b2), d(occ), d(t1), d(t2), d(frame), d(mask),
-              *dims, f, int(dilation), _lib.stream_ptr(),
+              *dims, f, int(dilation), *extra, _lib.stream_ptr(),
               work=("byte", float(n) * h * w * (6 * f * f * 4 + 4 + 2 * 4 * c + 4 * c * (3 if want_sides else 1)
                                                  + (4 if want_mask else 0)), "adacof_fused_kernel"))
     return t1, t2, frame, mask

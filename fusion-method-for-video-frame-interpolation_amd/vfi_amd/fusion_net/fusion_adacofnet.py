@@ -83,7 +83,8 @@ class KernelEstimation(PackedModule):
         """Upsample(x2, align_corners=True) -> conv -> ReLU, + skip (fusion_adacofnet.py:28-33,128-146)."""
         return ops.conv2d(x, pc, "zeros", "relu", residual=skip, upsample2x=True)
 
-    def forward_x6(self, x6):
+    def forward_x6(self, x6, softmax=True):
+        """softmax=False returns the Subnet_weight LOGITS (the sampler folds the softmax in)."""
         p = self.packed()
         c1 = self._basic(p["moduleConv1"], x6)
         c2 = self._basic(p["moduleConv2"], ops.pool2(c1, False))
@@ -104,7 +105,9 @@ class KernelEstimation(PackedModule):
             t = ops.conv2d(t, c_up, "zeros", "relu")
             # Upsample(x2, align_corners=True) -> conv: one launch, the upsampled tensor is never written
             if name.startswith("moduleWeight"):
-                t = ops.softmax_channels_(ops.conv2d(t, c_out, "zeros", None, upsample2x=True))
+                t = ops.conv2d(t, c_out, "zeros", None, upsample2x=True)
+                if softmax:
+                    t = ops.softmax_channels_(t)
             elif name == "moduleOcclusion":
                 t = ops.conv2d(t, c_out, "zeros", "sigmoid", upsample2x=True)
             else:
@@ -138,8 +141,9 @@ class AdaCoFNet(torch.nn.Module):
         if h0 != int(frame2.shape[2]) or w0 != int(frame2.shape[3]):
             sys.exit("Frame sizes do not match")                                 # fusion_adacofnet.py:177-178
         pad0, pad2, x6 = ops.adacof_prepare(frame0.contiguous(), frame2.contiguous(), rgbx=True)
-        w1, a1, b1, w2, a2, b2, occ = self.get_kernel.forward_x6(x6)
-        t1, t2, frame1, mask = adacof_fused(pad0, pad2, w1, a1, b1, w2, a2, b2, occ, self.dilation, rgbx=True)
+        w1, a1, b1, w2, a2, b2, occ = self.get_kernel.forward_x6(x6, softmax=False)
+        t1, t2, frame1, mask = adacof_fused(pad0, pad2, w1, a1, b1, w2, a2, b2, occ, self.dilation, rgbx=True,
+                                            weights_are_logits=True)
         if x6.shape[2] != h0 or x6.shape[3] != w0:
             # the reference's width crop assigns tensorAdaCoF1 from tensorAdaCoF2 (fusion_adacofnet.py:225);
             # both are unused downstream -- we return the correctly cropped t1.

@@ -83,12 +83,14 @@ int vfi_adacof_fused(const float *frame0, const float *frame2,
 
 /* Same computation on PIXEL-INTERLEAVED frames (N, H, W, 4) = (r, g, b, unused), as written by
  * vfi_adacof_prepare(..., rgbx=1): one 16-byte gather per bilinear corner instead of three 4-byte ones
- * (the kernel is bound by gather issue, not by HBM).  Outputs stay planar (N, 3, H, W). */
+ * (the kernel is bound by gather issue, not by HBM).  Outputs stay planar (N, 3, H, W).
+ * weights_are_logits != 0: w1 / w2 are the pre-softmax outputs of Subnet_weight and the channel softmax
+ * (fusion_adacofnet.py:56) is folded into the accumulation, so the normalised weights never touch HBM. */
 int vfi_adacof_fused_rgbx(const float *frame0_rgbx, const float *frame2_rgbx,
                           const float *w1, const float *a1, const float *b1,
                           const float *w2, const float *a2, const float *b2, const float *occ,
                           float *out_t1, float *out_t2, float *out_frame, float *out_mask,
-                          int N, int H, int W, int F, int dilation, vfi_stream_t stream);
+                          int N, int H, int W, int F, int dilation, int weights_are_logits, vfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense convolution on the fp32 matrix cores (exact fp32, v_mfma_f32_32x32x2_f32)

@@ -141,6 +141,13 @@ def test_fused_rgbx_equals_planar(device):
                        rgbx=True)
     for a, b in zip(ref, got):
         assert (a - b).abs().max().item() <= 1e-6
+    # softmax folded into the sampler: logits in, same outputs
+    lg1 = torch.log(d["w1"]) + 3.0 + torch.randn(2, 1, 40, 72, device=device) * 20.0   # shifts cancel in softmax
+    lg2 = torch.log(d["w2"]) - 50.0
+    got2 = adacof_fused(inter(d["f0"]), inter(d["f2"]), lg1.contiguous(), d["a1"], d["b1"], lg2.contiguous(), d["a2"], d["b2"],
+                        d["occ"], 1, rgbx=True, weights_are_logits=True)
+    for a, b in zip(ref, got2):
+        assert (a - b).abs().max().item() <= 2e-5
     # and the prologue writes that layout (reflect pad to /32 + mean-subtracted concat)
     f0, f2 = d["f0"][:, :, :, :70].contiguous(), d["f2"][:, :, :, :70].contiguous()
     p0, p2, x6 = ops.adacof_prepare(f0, f2, rgbx=True)

@@ -66,3 +66,21 @@ def test_glue_ops(device):
     assert (got - a.mean(1) * 30).abs().max().item() <= 1e-5
     got = ops.absdiff(a.to(device), b.to(device), 5.0, True).cpu()
     assert (got - ((a - b).abs() * 5).clamp(0, 1)).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("hi,wi,ho,wo,ac,relu", [(9, 15, 12, 20, False, False), (12, 20, 17, 29, False, False),
+                                                 (10, 12, 20, 24, True, False), (8, 12, 16, 24, False, True),
+                                                 (6, 11, 8, 15, False, False)])
+def test_resize_bilinear_matches_torch(hi, wi, ho, wo, ac, relu, device):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(hi * wo)
+    x = torch.randn((2, 5, hi, wi), generator=g)
+    res = torch.randn((2, 5, ho, wo), generator=g)
+    ref = F.interpolate(F.relu(x) if relu else x, size=(ho, wo), mode="bilinear", align_corners=ac) + res
+    got = ops.resize_bilinear(x.to(device), (ho, wo), align_corners=ac, relu_input=relu, residual=res.to(device))
+    assert (got.cpu() - ref).abs().max().item() <= 2e-6
+    # into a channel slice of a wider tensor (PhaseNet block input)
+    wide = torch.zeros((2, 9, ho, wo), device=device)
+    ops.resize_bilinear(x.to(device), (ho, wo), align_corners=ac, relu_input=relu, out=wide[:, 2:7])
+    ref2 = F.interpolate(F.relu(x) if relu else x, size=(ho, wo), mode="bilinear", align_corners=ac)
+    assert (wide[:, 2:7].cpu() - ref2).abs().max().item() <= 2e-6 and wide[:, :2].abs().max().item() == 0
