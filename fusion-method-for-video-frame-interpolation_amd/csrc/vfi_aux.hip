@@ -132,6 +132,42 @@ __global__ void resize_bilinear_vec4_kernel(const float *__restrict__ x, long lo
     }
 }
 
+// ---- single-output-channel `Upsample(x2, align_corners=True) -> Conv2d(C, 1, 3, padding=1)` tail ------------------
+// (Subnet_occlusion: fusion_adacofnet.py:68-70).  Both maps are linear, so conv(U(x)) = sum_t shift_t(U(m_t)) with
+// m_t = sum_c w[c][t] x_c a 1x1 convolution at LOW resolution (done by vfi_conv2d).  This kernel finishes:
+// out(y,x) = act(bias + sum_t bilinear(m_t; y+dy_t, x+dx_t)), taps falling outside the output are zero (padding).
+__global__ void upsample_tapsum_kernel(const float *__restrict__ m, float *__restrict__ out, int N, int Hs, int Ws,
+                                       float bias, int act) {
+    const int H = 2 * Hs, W = 2 * Ws;
+    const float sy = H > 1 ? (float)(Hs - 1) / (float)(H - 1) : 0.0f, sx = W > 1 ? (float)(Ws - 1) / (float)(W - 1) : 0.0f;
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = i % W, y = (i / W) % H, n = i / ((long long)W * H);
+        const float *mp = m + (size_t)n * 9 * Hs * Ws;
+        float acc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            if (yy < 0 || yy >= H) continue;
+            const float fy = sy * (float)yy;
+            const int y0 = (int)fy, y1 = min(y0 + 1, Hs - 1);
+            const float ly = fy - (float)y0;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = x + kx - 1;
+                if (xx < 0 || xx >= W) continue;
+                const float fx = sx * (float)xx;
+                const int x0 = (int)fx, x1 = min(x0 + 1, Ws - 1);
+                const float lx = fx - (float)x0;
+                const float *p = mp + (size_t)(ky * 3 + kx) * Hs * Ws;
+                acc += (1.0f - ly) * ((1.0f - lx) * p[y0 * Ws + x0] + lx * p[y0 * Ws + x1]) +
+                       ly * ((1.0f - lx) * p[y1 * Ws + x0] + lx * p[y1 * Ws + x1]);
+            }
+        }
+        out[i] = act == 4 ? 1.0f / (1.0f + expf(-acc)) : (act == 1 ? fmaxf(acc, 0.0f) : acc);
+    }
+}
+
 // ---- softmax over the channel axis (Subnet_weight: fusion_adacofnet.py:56) -----------------------------
 __global__ void softmax_channels_kernel(const float *__restrict__ x, long long x_bs, float *__restrict__ y,
                                         long long y_bs, int N, int C, int HW) {
@@ -338,4 +374,13 @@ extern "C" int vfi_tanh_residual_clamp(const float *x, const float *base, float 
     VFI_REQUIRE(count > 0, VFI_ERR_INVALID_ARG, "vfi_tanh_residual_clamp: bad size");
     LAUNCH_1D(tanh_residual_clamp_kernel, count, stream, x, base, y, count);
     return vfi::check_launch("vfi_tanh_residual_clamp");
+}
+
+extern "C" int vfi_upsample2x_tapsum(const float *taps_lowres, float *out, int N, int Hs, int Ws, float bias, int act,
+                                     vfi_stream_t stream) {
+    VFI_REQUIRE(taps_lowres && out, VFI_ERR_INVALID_ARG, "vfi_upsample2x_tapsum: null pointer");
+    VFI_REQUIRE(N > 0 && Hs > 0 && Ws > 0, VFI_ERR_INVALID_ARG, "vfi_upsample2x_tapsum: bad sizes");
+    VFI_REQUIRE(act == 0 || act == 1 || act == 4, VFI_ERR_UNSUPPORTED, "vfi_upsample2x_tapsum: act %d", act);
+    LAUNCH_1D(upsample_tapsum_kernel, (long long)N * 4 * Hs * Ws, stream, taps_lowres, out, N, Hs, Ws, bias, act);
+    return vfi::check_launch("vfi_upsample2x_tapsum");
 }

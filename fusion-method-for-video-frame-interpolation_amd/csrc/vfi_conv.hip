@@ -118,6 +118,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
         in_c[i] = c;
     }
     const int HWs = UPS ? a.Hs * a.Ws : HW;   // channel stride of x
+    // UPS: chunk-invariant top-left source offset (relative to the chunk's first channel) per element, with the
+    // +1 column / +1 row steps packed beside the channel index: a chunk's staging then costs ~25 VALU per
+    // element instead of ~55 (the loader's VALU work does not overlap the same wave's MFMAs)
+    int uo[UPS ? T::IN_PER_THREAD : 1];
+    if constexpr (UPS) {
+#pragma unroll
+        for (int i = 0; i < T::IN_PER_THREAD; ++i) {
+            const int pk = max(in_off[i], 0);
+            const int gy = pk >> 16, gx = pk & 0xffff;
+            const int sy0 = (int)(a.ups_sy * (float)gy), sx0 = (int)(a.ups_sx * (float)gx);
+            const int dx = sx0 + 1 <= a.Ws - 1 ? 1 : 0, dy = sy0 + 1 <= a.Hs - 1 ? 1 : 0;
+            uo[i] = in_c[i] * HWs + sy0 * a.Ws + sx0;
+            in_c[i] |= (dx << 8) | (dy << 9);
+        }
+    }
     const float *xn = a.x + (size_t)n * a.x_bs;
     const float *wn = a.wp + (size_t)nb * T::BN;
 
@@ -131,19 +146,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
         const int cbase = ch * CK;
 #pragma unroll
         for (int i = 0; i < T::IN_PER_THREAD; ++i) {
-            const bool ok = in_off[i] >= 0 && (cbase + in_c[i]) < a.Cin;
+            const bool ok = in_off[i] >= 0 && (cbase + (in_c[i] & 0xff)) < a.Cin;
             if constexpr (UPS) {
-                // always-valid addresses (coordinates / channel clamped), 32-bit offsets from the wave-uniform
-                // sample base; padding and the channel tail are zeroed when the tile is written to LDS
-                const int pk = max(in_off[i], 0);
-                const int gy = pk >> 16, gx = pk & 0xffff;
-                const int sy0 = (int)(a.ups_sy * (float)gy), sx0 = (int)(a.ups_sx * (float)gx);
-                const int sy1 = min(sy0 + 1, a.Hs - 1), sx1 = min(sx0 + 1, a.Ws - 1);
-                const int cb = min(cbase + in_c[i], a.Cin - 1) * HWs;
-                in_reg[0][i] = xn[cb + sy0 * a.Ws + sx0];
-                in_reg[1][i] = xn[cb + sy0 * a.Ws + sx1];
-                in_reg[2][i] = xn[cb + sy1 * a.Ws + sx0];
-                in_reg[3][i] = xn[cb + sy1 * a.Ws + sx1];
+                // padding / channel-tail elements read offset 0 of the chunk (a valid address) and are zeroed
+                // when the tile is written to LDS
+                const int o0 = ok ? uo[i] : 0;
+                const int ddx = ok ? ((in_c[i] >> 8) & 1) : 0, ddy = (ok && ((in_c[i] >> 9) & 1)) ? a.Ws : 0;
+                in_reg[0][i] = xc[o0];
+                in_reg[1][i] = xc[o0 + ddx];
+                in_reg[2][i] = xc[o0 + ddy];
+                in_reg[3][i] = xc[o0 + ddy + ddx];
             } else {
                 const float *p = ok ? xc + in_off[i] : &g_zero_word;
                 in_reg[0][i] = *p;
@@ -157,12 +169,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
             float v = in_reg[0][i];
             if constexpr (UPS) {   // torch upsample_bilinear2d: h0l*(w0l*v00 + w1l*v01) + h1l*(w0l*v10 + w1l*v11)
                 const int pk = max(in_off[i], 0);
-                const int gy = pk >> 16, gx = pk & 0xffff;
-                const float fy = a.ups_sy * (float)gy, fx = a.ups_sx * (float)gx;
+                const float fy = a.ups_sy * (float)(pk >> 16), fx = a.ups_sx * (float)(pk & 0xffff);
                 const float ly = fy - (float)(int)fy, lx = fx - (float)(int)fx;
                 v = (1.0f - ly) * ((1.0f - lx) * in_reg[0][i] + lx * in_reg[1][i]) +
                     ly * ((1.0f - lx) * in_reg[2][i] + lx * in_reg[3][i]);
-                v = (in_off[i] >= 0 && ch * CK + in_c[i] < a.Cin) ? v : 0.0f;
+                v = (in_off[i] >= 0 && ch * CK + (in_c[i] & 0xff) < a.Cin) ? v : 0.0f;
             }
             if (T::IN_ELEMS % 256 == 0 || e < T::IN_ELEMS) buf[e] = v;
         }

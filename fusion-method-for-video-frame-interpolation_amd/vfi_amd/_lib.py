@@ -30,6 +30,7 @@ SIGNATURES = {
     "vfi_adacof_fused_rgbx": [c_f] * 13 + [c_i] * 6 + [c_s],
     "vfi_pool2": [c_f, c_l, c_f, c_l] + [c_i] * 5 + [c_s],
     "vfi_resize_bilinear": [c_f, c_l, c_f, c_l, c_f, c_l] + [c_i] * 8 + [c_s],
+    "vfi_upsample2x_tapsum": [c_f, c_f, c_i, c_i, c_i, c_fl, c_i, c_s],
     "vfi_softmax_channels": [c_f, c_l, c_f, c_l] + [c_i] * 3 + [c_s],
     "vfi_affine_slice": [c_f, c_l, c_f, c_l, c_i, c_l, c_f, c_fl, c_s],
     "vfi_batch_max": [c_f, c_l, c_i, c_l, c_fl, c_f, c_f, c_s],

@@ -16,7 +16,7 @@ import sys
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from ..adacof.cupy_module.adacof import FunctionAdaCoF, adacof_fused
 from ..nn_util import ConvParams, Indexed, PackedModule
 
@@ -72,6 +72,11 @@ class KernelEstimation(PackedModule):
         for h in HEADS:
             m = getattr(self, h)
             p[h] = [self.pack(m[2]), self.pack(m[4]), self.pack(m[7])]
+        # occlusion tail Upsample -> Conv2d(64, 1, 3): channel reduction as a 1x1 conv (taps as output channels) at
+        # low resolution, finished by vfi_upsample2x_tapsum (exact by linearity)
+        w7 = self.moduleOcclusion[7].weight                              # (1, 64, 3, 3)
+        p["occ_taps"] = ops.PackedConv(w7[0].permute(1, 2, 0).reshape(9, -1, 1, 1).contiguous(), None)
+        p["occ_bias"] = float(self.moduleOcclusion[7].bias.item())
         return p
 
     def _basic(self, convs, x):
@@ -109,7 +114,10 @@ class KernelEstimation(PackedModule):
                 if softmax:
                     t = ops.softmax_channels_(t)
             elif name == "moduleOcclusion":
-                t = ops.conv2d(t, c_out, "zeros", "sigmoid", upsample2x=True)
+                taps = ops.conv2d(t, p["occ_taps"], "zeros", None)                  # (N, 9, h, w)
+                t = ops.new((n, 1, 2 * h, 2 * w), t)
+                _lib.call("vfi_upsample2x_tapsum", taps.data_ptr(), t.data_ptr(), n, h, w, p["occ_bias"], 4,
+                          _lib.stream_ptr())
             else:
                 t = ops.conv2d(t, c_out, "zeros", None, upsample2x=True)
             outs.append(t)

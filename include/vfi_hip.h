@@ -161,6 +161,14 @@ int vfi_resize_bilinear(const float *x, long long x_bstride, const float *residu
                         float *y, long long y_bstride, int N, int C, int Hin, int Win, int Hout, int Wout,
                         int align_corners, int relu_input, vfi_stream_t stream);
 
+/* Tail of `Upsample(x2, bilinear, align_corners=True) -> Conv2d(C, 1, 3, padding=1) -> act` (Subnet_occlusion,
+ * fusion_adacofnet.py:68-70) after the channel reduction has been done at LOW resolution: taps_lowres (N,9,Hs,Ws)
+ * holds m_t = sum_c w[0][c][t] * x_c (a 1x1 vfi_conv2d with the 3x3 filter's taps as output channels);
+ * out (N,1,2Hs,2Ws) = act(bias + sum_t U(m_t) shifted by tap t, zero outside).  Exact by linearity of both maps;
+ * replaces a 64->1 conv at full resolution that would waste 31/32 of each matrix-core tile. */
+int vfi_upsample2x_tapsum(const float *taps_lowres, float *out, int N, int Hs, int Ws, float bias, int act,
+                          vfi_stream_t stream);
+
 /* Softmax over the channel axis of (N,C,HW) (Subnet_weight, fusion_adacofnet.py:56).  In place allowed. */
 int vfi_softmax_channels(const float *x, long long x_bstride, float *y, long long y_bstride, int N, int C, int HW,
                          vfi_stream_t stream);

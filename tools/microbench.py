@@ -78,6 +78,14 @@ def main():
             tot_f += fl; tot_t += t
             print(f"{name:28s} {t*1e3:8.3f} ms  {fl/t/1e12:7.2f} TFLOP/s", flush=True)
         print(f"{'total':28s} {tot_t*1e3:8.3f} ms  {tot_f/tot_t/1e12:7.2f} TFLOP/s")
+        for name, n, cin, cout, hs, ws in [("ups head7 25->25 ->1088x1920", 1, 25, 25, 544, 960), ("ups occ 64->1", 1, 64, 1, 544, 960),
+                                           ("ups up2 64->64 ->544x960", 1, 64, 64, 272, 480), ("ups up4 256->256 ->136x240", 1, 256, 256, 68, 120)]:
+            x = torch.randn((n, cin, hs, ws), device=dev)
+            pc = ops.PackedConv(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5, torch.zeros(cout), device=dev)
+            out = torch.empty((n, cout, 2 * hs, 2 * ws), device=dev)
+            t = timeit(lambda: ops.conv2d(x, pc, "zeros", "relu", out=out, upsample2x=True), iters=args.iters)
+            fl = 2.0 * n * cin * cout * 9 * 4 * hs * ws
+            print(f"{name:28s} {t*1e3:8.3f} ms  {fl/t/1e12:7.2f} TFLOP/s", flush=True)
 
 
 def bench_adacof(dev):
