@@ -42,6 +42,9 @@ struct ConvArgs {
     int Cin, Cin_pad, Cout, Cout_pad, H, W, tiles_x;
     int pad_mode;  // 0 zero, 1 reflect
     int act;       // vfi_act
+    long long ws_floats;
+    float *ws;     // split-K partial sums [splits][N][Cout][H][W] (splits > 1)
+    int splits;    // K (input-channel chunk) range split over `splits` workgroups per output tile
     int Hs, Ws;    // UPS kernels: size of the low-resolution source x (H = 2*Hs, W = 2*Ws)
     float ups_sy, ups_sx;   // (Hs-1)/(H-1), (Ws-1)/(W-1): torch bilinear, align_corners=True
 };
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
     const int wave = tid >> 6;
     const int khalf = lane >> 5, l31 = lane & 31;
     const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
-    const int nb = blockIdx.y, n = blockIdx.z;
+    const int nb = blockIdx.y, n = blockIdx.z / a.splits, split = blockIdx.z % a.splits;
     const int x0 = tile_x * T::TW, y0 = tile_y * T::TH;
     const int HW = a.H * a.W;
 
@@ -203,19 +206,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[nt][rr][q] = 0.0f;
 
-    const int nchunks = a.Cin_pad / CK;
-    load_weights_async(0, lds);
-    load_inputs(0);
-    store_inputs(lds, 0);
+    // this workgroup's range of input-channel chunks (all of them unless the launch is split over K)
+    const int nchunks_all = a.Cin_pad / CK;
+    const int ch_begin = (int)((long long)nchunks_all * split / a.splits);
+    const int nchunks = (int)((long long)nchunks_all * (split + 1) / a.splits);
+    load_weights_async(ch_begin, lds);
+    load_inputs(ch_begin);
+    store_inputs(lds, ch_begin);
     __syncthreads();
 
     const int b_base = khalf * T::PLANE + (RW * wave) * T::PW + l31;
     const int a_base = khalf * T::TAPS * T::BN + l31;
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float *buf = lds + (ch & 1) * T::BUF;
+    for (int ch = ch_begin; ch < nchunks; ++ch) {
+        const float *buf = lds + ((ch - ch_begin) & 1) * T::BUF;
+        float *nxt = lds + ((ch - ch_begin + 1) & 1) * T::BUF;
         if (ch + 1 < nchunks) {
-            load_weights_async(ch + 1, lds + ((ch + 1) & 1) * T::BUF);
+            load_weights_async(ch + 1, nxt);
             load_inputs(ch + 1);
         }
         const float *in_s = buf + b_base;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
                 for (int rr = 0; rr < RW; ++rr)
                     acc[nt][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sidx & 1][nt], bf[sidx & 1][rr], acc[nt][rr], 0, 0, 0);
         }
-        if (ch + 1 < nchunks) store_inputs(lds + ((ch + 1) & 1) * T::BUF, ch + 1);
+        if (ch + 1 < nchunks) store_inputs(nxt, ch + 1);
         __syncthreads();
     }
 
@@ -253,6 +260,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
     // All bias / residual loads of a 32x32 tile are issued together before the first store (a load inside
     // the store loop is waited for individually: 16*NT serialized round trips per lane).
     const int gx = x0 + l31;
+    if (a.splits > 1) {   // split-K: raw partial sums; bias / activation / residual are applied by the reduce kernel
+        float *__restrict__ wsp = a.ws + ((size_t)split * gridDim.z / a.splits + n) * a.Cout * HW;
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int gy = y0 + RW * wave + rr;
+            if (gy >= a.H || gx >= a.W) continue;
+            const size_t pix = (size_t)gy * a.W + gx;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = nb * T::BN + nt * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+                    if (co < a.Cout) wsp[(size_t)co * HW + pix] = acc[nt][rr][q];
+                }
+        }
+        return;
+    }
     const float *__restrict__ biasp = a.bias;
     const float *__restrict__ resp = a.res ? a.res + (size_t)n * a.res_bs : nullptr;
     float *__restrict__ yp = a.y + (size_t)n * a.y_bs;
@@ -283,6 +307,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
                 if (co < a.Cout) yp[(size_t)co * HW + pix] = apply_act(acc[nt][rr][q] + bv[nt][q], a.act) + rv[q];
             }
         }
+    }
+}
+
+// y = act(sum_s ws[s] + bias) + residual   (deterministic split-K reduction)
+__global__ void conv2d_splitk_reduce_kernel(const float *__restrict__ ws, int splits, const float *__restrict__ bias,
+                                            const float *__restrict__ res, long long res_bs, float *__restrict__ y,
+                                            long long y_bs, int N, int Cout, int HW, int act) {
+    const long long per = (long long)Cout * HW, total = (long long)N * per;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i % per;
+        const int n = i / per, co = e / HW;
+        float v = 0.0f;
+        for (int sidx = 0; sidx < splits; ++sidx) v += ws[(size_t)sidx * total + i];
+        if (bias) v += bias[co];
+        v = apply_act(v, act);
+        if (res) v += res[(size_t)n * res_bs + e];
+        y[(size_t)n * y_bs + e] = v;
     }
 }
 
@@ -317,8 +358,30 @@ int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
         attr_done = true;
     }
     const int tiles_y = vfi::ceil_div(a.H, T::TH);
-    dim3 grid(a.tiles_x * tiles_y, a.Cout_pad / T::BN, N);
-    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, CK, NT, UPS, RW>), grid, dim3(256), T::LDS_BYTES, s, a);
+    const long long blocks = (long long)a.tiles_x * tiles_y * (a.Cout_pad / T::BN) * N;
+    // Split-K: 2 workgroups are resident per CU (512 slots); a launch of B workgroups takes ceil(B/512) rounds, so
+    // few / long workgroups (deep U-Net levels) leave most of a round idle.  Splitting the channel loop S ways
+    // makes S*B workgroups of 1/S the length; partial sums go to the caller's workspace and are reduced
+    // deterministically.  Pick the S with the fewest full-round equivalents, if it saves >= 15 %.
+    ConvArgs b = a;
+    b.splits = 1;
+    const int nchunks = a.Cin_pad / CK;
+    const long long out_floats = (long long)N * a.Cout * a.H * a.W;
+    if (a.ws && nchunks >= 8 && blocks < 4 * 512) {
+        auto cost = [&](int S) { return (double)((blocks * S + 511) / 512) / S; };
+        int best = 1;
+        for (int S = 2; S <= 16; S *= 2)
+            if (nchunks / S >= 2 && out_floats * S <= a.ws_floats && cost(S) < cost(best) - 1e-9) best = S;
+        if (cost(best) <= 0.85 * cost(1)) b.splits = best;
+    }
+    dim3 grid(a.tiles_x * tiles_y, a.Cout_pad / T::BN, N * b.splits);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, CK, NT, UPS, RW>), grid, dim3(256), T::LDS_BYTES, s, b);
+    if (b.splits > 1) {
+        const long long tot = out_floats;
+        const int rb = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+        hipLaunchKernelGGL(conv2d_splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, b.ws, b.splits, b.bias, b.res, b.res_bs,
+                           b.y, b.y_bs, N, b.Cout, b.H * b.W, b.act);
+    }
     return vfi::check_launch("vfi_conv2d");
 }
 
@@ -343,7 +406,8 @@ extern "C" int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *p
 
 static int conv2d_impl(const float *x, long long x_bstride, const float *packed_w, const float *bias,
                        const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
-                       int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, bool ups, vfi_stream_t stream) {
+                       int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, bool ups, float *workspace,
+                       long long workspace_floats, vfi_stream_t stream) {
     VFI_REQUIRE(x && packed_w && y, VFI_ERR_INVALID_ARG, "vfi_conv2d: null pointer");
     VFI_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, VFI_ERR_INVALID_ARG, "vfi_conv2d: non-positive size");
     VFI_REQUIRE(KS == 1 || KS == 3 || KS == 5, VFI_ERR_UNSUPPORTED, "vfi_conv2d: kernel size %d", KS);
@@ -361,6 +425,7 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     a.Cin = Cin; a.Cin_pad = round_up(Cin, 8); a.Cout = Cout; a.Cout_pad = round_up(Cout, 32);
     a.H = H; a.W = W; a.tiles_x = vfi::ceil_div(W, 32);
     a.pad_mode = pad_mode; a.act = act;
+    a.ws = workspace_floats > 0 ? workspace : nullptr; a.ws_floats = workspace ? workspace_floats : 0; a.splits = 1;
     a.Hs = H / 2; a.Ws = W / 2;
     a.ups_sy = H > 1 ? (float)(a.Hs - 1) / (float)(H - 1) : 0.0f;
     a.ups_sx = W > 1 ? (float)(a.Ws - 1) / (float)(W - 1) : 0.0f;
@@ -381,14 +446,16 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
 
 extern "C" int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,
                           const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
-                          int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream) {
+                          int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, float *workspace,
+                          long long workspace_floats, vfi_stream_t stream) {
     return conv2d_impl(x, x_bstride, packed_w, bias, residual, res_bstride, y, y_bstride, N, Cin, H, W, Cout, KS,
-                       pad_mode, act, false, stream);
+                       pad_mode, act, false, workspace, workspace_floats, stream);
 }
 
 extern "C" int vfi_conv2d_upsample2x(const float *x_lowres, long long x_bstride, const float *packed_w, const float *bias,
                                      const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
-                                     int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream) {
+                                     int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, float *workspace,
+                                     long long workspace_floats, vfi_stream_t stream) {
     return conv2d_impl(x_lowres, x_bstride, packed_w, bias, residual, res_bstride, y, y_bstride, N, Cin, H, W, Cout, KS,
-                       pad_mode, act, true, stream);
+                       pad_mode, act, true, workspace, workspace_floats, stream);
 }

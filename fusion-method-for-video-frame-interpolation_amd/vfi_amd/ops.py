@@ -65,6 +65,19 @@ class PackedConv:
         self._keep = (weight, scale)  # alive until the pack kernel has run (same stream ordering)
 
 
+_WORKSPACES = {}
+WORKSPACE_FLOATS = 48 * 1024 * 1024     # 192 MiB per (device, stream): split-K partial sums of the deep U-Net levels
+
+
+def _workspace(device):
+    """Split-K scratch, one per (device, stream) so frames in flight on different streams never share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = torch.empty(WORKSPACE_FLOATS, dtype=torch.float32, device=device)
+    return ws
+
+
 def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2x=False):
     """act(conv(x) + bias) (+ residual) -> out.  One vfi_conv2d launch.  upsample2x: x is the low-resolution
     input of an `Upsample(x2, bilinear, align_corners=True) -> conv` pair (the upsampled tensor is not
@@ -85,13 +98,14 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2
         if tuple(residual.shape) != tuple(out.shape):
             raise VfiLibraryError("conv2d: residual shape mismatch")
         rp, rs = _slice_ptr(residual, "residual")
+    ws = _workspace(x.device)
     work = None
     if _lib.PROFILE is not None:
         label = (f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}"
                  + (",ups>" if upsample2x else ">"))
         work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w, label)
     _lib.call("vfi_conv2d_upsample2x" if upsample2x else "vfi_conv2d", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), rp, rs, yp, ys,
-              n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], _lib.stream_ptr(), work=work)
+              n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], ws.data_ptr(), ws.numel(), _lib.stream_ptr(), work=work)
     return out
 
 

@@ -123,10 +123,16 @@ int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int 
  *   x        (N, Cin, H, W); consecutive samples are x_bstride floats apart, so x may be a channel
  *            slice of a wider tensor (no concat / split copies)
  *   residual NULL or (N, Cout, H, W) with stride res_bstride, added AFTER the activation
- *   y        (N, Cout, H, W) with stride y_bstride */
+ *   y        (N, Cout, H, W) with stride y_bstride
+ *   workspace / workspace_floats  optional scratch (NULL / 0 = none).  When the launch would otherwise fill only a
+ *            fraction of a round of resident workgroups (deep U-Net levels: few, long workgroups) the channel
+ *            loop is split over several workgroups whose partial sums go through the workspace and are reduced
+ *            in a fixed order (deterministic).  16 * N*Cout*H*W floats always suffice; results do not depend on
+ *            whether a workspace is given beyond fp32 summation order. */
 int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,
                const float *residual, long long res_bstride, float *y, long long y_bstride, int N, int Cin,
-               int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream);
+               int H, int W, int Cout, int KS, int pad_mode, int act, float *workspace,
+               long long workspace_floats, vfi_stream_t stream);
 
 /* conv2d( nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)(x_lowres) ) in one launch: the
  * `Upsample -> Conv2d` pairs of KernelEstimation (src/fusion_net/fusion_adacofnet.py:28-33 and the heads'
@@ -134,7 +140,8 @@ int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const
  * tensor is never written to HBM (the tile loader interpolates it).  KS = 3, zero padding only. */
 int vfi_conv2d_upsample2x(const float *x_lowres, long long x_bstride, const float *packed_w, const float *bias,
                           const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
-                          int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, vfi_stream_t stream);
+                          int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, float *workspace,
+                          long long workspace_floats, vfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Glue between the convolutions (HBM-bound; batch strides as for vfi_conv2d)

@@ -54,6 +54,29 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.what == "unet":
+        import types
+        from vfi_amd import _lib
+        from vfi_amd.fusion_net.fusion_adacofnet import AdaCoFNet
+        net = AdaCoFNet(types.SimpleNamespace(kernel_size=5, dilation=1, gpu_id=0)).to(dev)
+        n = int(args.filter or 1)
+        f0, f2 = torch.rand((n, 3, 1080, 1920), device=dev), torch.rand((n, 3, 1080, 1920), device=dev)
+        for _ in range(2):
+            net(f0, f2)
+        torch.cuda.synchronize()
+        _lib.PROFILE = _lib.Recorder()
+        net(f0, f2)
+        torch.cuda.synchronize()
+        tot = 0.0
+        for name, work, e0, e1 in _lib.PROFILE.rows:
+            t = e0.elapsed_time(e1)
+            tot += t
+            if work and work[0] == "flop":
+                print(f"{work[2]:34s} {t:7.3f} ms {work[1]/1e9:8.1f} GF {work[1]/t/1e9:7.1f} TF/s")
+            else:
+                print(f"{name:34s} {t:7.3f} ms")
+        print("total", tot)
+        _lib.PROFILE = None
     if args.what == "adacof":
         bench_adacof(dev)
     if args.what == "median":
