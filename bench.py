@@ -106,8 +106,9 @@ def main():
     rank, local_rank, world = shard.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()     # (== local_rank on a real node; lets 2 ranks rehearse on 1 GPU)
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     h, w = args.height, args.width
 
     runners, n_weights = build_runner(device, args.streams)

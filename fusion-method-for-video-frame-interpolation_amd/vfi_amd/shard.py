@@ -23,7 +23,7 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("VFI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -48,7 +48,12 @@ def broadcast_module_states(modules, src=0):
         return 0
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(flat, src=src)
+        if dist.get_backend() == "gloo" and flat.is_cuda:     # CPU rehearsal backend: stage through host memory
+            host = flat.cpu()
+            dist.broadcast(host, src=src)
+            flat = host.to(flat.device)
+        else:
+            dist.broadcast(flat, src=src)
     off = 0
     for t in tensors:
         n = t.numel()
@@ -67,6 +72,8 @@ def reduce_counters(frames, seconds, device):
     """-> (total frames over all ranks, max seconds over ranks)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return frames, seconds
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([float(frames)], dtype=torch.float64, device=device)
     s = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
