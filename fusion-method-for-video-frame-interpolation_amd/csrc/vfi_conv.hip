@@ -45,6 +45,9 @@ struct ConvArgs {
     long long ws_floats;
     float *ws;     // split-K partial sums [splits][N][Cout][H][W] (splits > 1)
     int splits;    // K (input-channel chunk) range split over `splits` workgroups per output tile
+    const float *x2;       // SRC = 2: tensor whose resize forms the first rsz_channels input channels
+    long long x2_bs;
+    int rsz_channels;      // multiple of CK
     int Hs, Ws;    // UPS kernels: size of the low-resolution source x (H = 2*Hs, W = 2*Ws)
     float ups_sy, ups_sx;   // (Hs-1)/(H-1), (Ws-1)/(W-1): torch bilinear, align_corners=True
 };
@@ -84,11 +87,22 @@ struct ConvTile {
     static constexpr size_t LDS_BYTES = 2ull * BUF * sizeof(float);
 };
 
+// source coordinate of output index g: SRC 1 = align_corners=True (scale*(g)), SRC 2 = align_corners=False
+template <int SRC>
+__device__ __forceinline__ float src_coord(float scale, int g) {
+    return SRC == 1 ? scale * (float)g : fmaxf(scale * ((float)g + 0.5f) - 0.5f, 0.0f);
+}
+
 // UPS: the conv input is nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)(x) and is never
 // materialised -- the tile loader interpolates it from the low-resolution x (4 loads + lerp per element).
-template <int KS, int CK, int NT, bool UPS = false, int RW = 2>
+// SRC = 1 (see above); SRC = 2: the first `rsz_channels` input channels are torch's bilinear resize
+// (align_corners=False, arbitrary ratio) of a second tensor x2 (N, rsz_channels, Hs, Ws), the remaining channels
+// come from x itself -- PhaseNet's `cat(Upsample(feature), phase, amp, Upsample(prediction))` block input
+// (src/phase_net/phase_net.py:138-141) without materialising the resized maps.
+template <int KS, int CK, int NT, int SRC = 0, int RW = 2>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
     using T = ConvTile<KS, CK, NT, RW>;
+    constexpr bool UPS = SRC != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -130,13 +144,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
         for (int i = 0; i < T::IN_PER_THREAD; ++i) {
             const int pk = max(in_off[i], 0);
             const int gy = pk >> 16, gx = pk & 0xffff;
-            const int sy0 = (int)(a.ups_sy * (float)gy), sx0 = (int)(a.ups_sx * (float)gx);
+            const int sy0 = min((int)src_coord<SRC>(a.ups_sy, gy), a.Hs - 1), sx0 = min((int)src_coord<SRC>(a.ups_sx, gx), a.Ws - 1);
             const int dx = sx0 + 1 <= a.Ws - 1 ? 1 : 0, dy = sy0 + 1 <= a.Hs - 1 ? 1 : 0;
             uo[i] = in_c[i] * HWs + sy0 * a.Ws + sx0;
             in_c[i] |= (dx << 8) | (dy << 9);
         }
     }
     const float *xn = a.x + (size_t)n * a.x_bs;
+    const float *x2n = SRC == 2 ? a.x2 + (size_t)n * a.x2_bs : xn;   // source of the resized channels
     const float *wn = a.wp + (size_t)nb * T::BN;
 
     float in_reg[UPS ? 4 : 1][T::IN_PER_THREAD];
@@ -145,20 +160,25 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
     // address and the value selected afterwards, so all loads of a chunk are in flight together and the
     // staging array stays in VGPRs) -> LDS after the chunk's MFMAs.
     auto load_inputs = [&](int ch) {
-        const float *xc = xn + (size_t)ch * CK * HWs;
         const int cbase = ch * CK;
+        const bool direct = SRC == 2 && cbase >= a.rsz_channels;          // wave-uniform
+        const float *xc = (SRC == 2 ? x2n : xn) + (size_t)ch * CK * HWs;
 #pragma unroll
         for (int i = 0; i < T::IN_PER_THREAD; ++i) {
             const bool ok = in_off[i] >= 0 && (cbase + (in_c[i] & 0xff)) < a.Cin;
             if constexpr (UPS) {
-                // padding / channel-tail elements read offset 0 of the chunk (a valid address) and are zeroed
-                // when the tile is written to LDS
-                const int o0 = ok ? uo[i] : 0;
-                const int ddx = ok ? ((in_c[i] >> 8) & 1) : 0, ddy = (ok && ((in_c[i] >> 9) & 1)) ? a.Ws : 0;
-                in_reg[0][i] = xc[o0];
-                in_reg[1][i] = xc[o0 + ddx];
-                in_reg[2][i] = xc[o0 + ddy];
-                in_reg[3][i] = xc[o0 + ddy + ddx];
+                // padding / channel-tail elements read a valid address and are zeroed when the tile is written to
+                // LDS; SRC = 2 chunks past the resized prefix read x itself (same 4 loads, zero steps: no branch)
+                const int pk = max(in_off[i], 0);
+                const int od = (cbase + (in_c[i] & 0xff)) * HW + (pk >> 16) * a.W + (pk & 0xffff);
+                const int o0 = ok ? (direct ? od : uo[i]) : 0;
+                const int ddx = (ok && !direct) ? ((in_c[i] >> 8) & 1) : 0;
+                const int ddy = (ok && !direct && ((in_c[i] >> 9) & 1)) ? a.Ws : 0;
+                const float *pb = direct ? xn : xc;
+                in_reg[0][i] = pb[o0];
+                in_reg[1][i] = pb[o0 + ddx];
+                in_reg[2][i] = pb[o0 + ddy];
+                in_reg[3][i] = pb[o0 + ddy + ddx];
             } else {
                 const float *p = ok ? xc + in_off[i] : &g_zero_word;
                 in_reg[0][i] = *p;
@@ -171,11 +191,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
             const int e = tid + 256 * i;
             float v = in_reg[0][i];
             if constexpr (UPS) {   // torch upsample_bilinear2d: h0l*(w0l*v00 + w1l*v01) + h1l*(w0l*v10 + w1l*v11)
-                const int pk = max(in_off[i], 0);
-                const float fy = a.ups_sy * (float)(pk >> 16), fx = a.ups_sx * (float)(pk & 0xffff);
-                const float ly = fy - (float)(int)fy, lx = fx - (float)(int)fx;
-                v = (1.0f - ly) * ((1.0f - lx) * in_reg[0][i] + lx * in_reg[1][i]) +
-                    ly * ((1.0f - lx) * in_reg[2][i] + lx * in_reg[3][i]);
+                if (!(SRC == 2 && ch * CK >= a.rsz_channels)) {
+                    const int pk = max(in_off[i], 0);
+                    const float fy = src_coord<SRC>(a.ups_sy, pk >> 16), fx = src_coord<SRC>(a.ups_sx, pk & 0xffff);
+                    const float ly = fy - (float)min((int)fy, a.Hs - 1), lx = fx - (float)min((int)fx, a.Ws - 1);
+                    v = (1.0f - ly) * ((1.0f - lx) * in_reg[0][i] + lx * in_reg[1][i]) +
+                        ly * ((1.0f - lx) * in_reg[2][i] + lx * in_reg[3][i]);
+                }
                 v = (in_off[i] >= 0 && ch * CK + (in_c[i] & 0xff) < a.Cin) ? v : 0.0f;
             }
             if (T::IN_ELEMS % 256 == 0 || e < T::IN_ELEMS) buf[e] = v;
@@ -347,7 +369,7 @@ __global__ void conv2d_pack_kernel(const float *__restrict__ w, const float *__r
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int KS, int CK, int NT, bool UPS = false, int RW = 2>
+template <int KS, int CK, int NT, int UPS = 0, int RW = 2>
 int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
     using T = ConvTile<KS, CK, NT, RW>;
     static bool attr_done = false;  // idempotent; racing threads set the same value
@@ -407,7 +429,8 @@ extern "C" int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *p
 static int conv2d_impl(const float *x, long long x_bstride, const float *packed_w, const float *bias,
                        const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
                        int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, bool ups, float *workspace,
-                       long long workspace_floats, vfi_stream_t stream) {
+                       long long workspace_floats, vfi_stream_t stream, const float *x2 = nullptr, long long x2_bstride = 0,
+                       int rsz_channels = 0, int Hs = 0, int Ws = 0) {
     VFI_REQUIRE(x && packed_w && y, VFI_ERR_INVALID_ARG, "vfi_conv2d: null pointer");
     VFI_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, VFI_ERR_INVALID_ARG, "vfi_conv2d: non-positive size");
     VFI_REQUIRE(KS == 1 || KS == 3 || KS == 5, VFI_ERR_UNSUPPORTED, "vfi_conv2d: kernel size %d", KS);
@@ -426,6 +449,7 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     a.H = H; a.W = W; a.tiles_x = vfi::ceil_div(W, 32);
     a.pad_mode = pad_mode; a.act = act;
     a.ws = workspace_floats > 0 ? workspace : nullptr; a.ws_floats = workspace ? workspace_floats : 0; a.splits = 1;
+    a.x2 = nullptr; a.x2_bs = 0; a.rsz_channels = 0;
     a.Hs = H / 2; a.Ws = W / 2;
     a.ups_sy = H > 1 ? (float)(a.Hs - 1) / (float)(H - 1) : 0.0f;
     a.ups_sx = W > 1 ? (float)(a.Ws - 1) / (float)(W - 1) : 0.0f;
@@ -434,7 +458,16 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     if (ups) {
         VFI_REQUIRE(KS == 3 && pad_mode == 0 && H % 2 == 0 && W % 2 == 0 && H < 65536 && W < 65536, VFI_ERR_UNSUPPORTED,
                     "vfi_conv2d_upsample2x: needs KS=3, zero padding, even output size (got KS=%d pad=%d %dx%d)", KS, pad_mode, H, W);
-        return wide ? launch_conv<3, 8, 2, true>(a, N, s) : launch_conv<3, 8, 1, true>(a, N, s);
+        return wide ? launch_conv<3, 8, 2, 1>(a, N, s) : launch_conv<3, 8, 1, 1>(a, N, s);
+    }
+    if (x2) {
+        VFI_REQUIRE(KS == 3 && wide && rsz_channels > 0 && rsz_channels % 8 == 0 && rsz_channels <= Cin && Hs > 0 && Ws > 0 &&
+                    H < 65536 && W < 65536, VFI_ERR_UNSUPPORTED,
+                    "vfi_conv2d_resized_prefix: needs KS=3, Cout%%64==0, prefix channels a multiple of 8 (got KS=%d Cout=%d prefix=%d)",
+                    KS, Cout, rsz_channels);
+        a.x2 = x2; a.x2_bs = x2_bstride; a.rsz_channels = rsz_channels; a.Hs = Hs; a.Ws = Ws;
+        a.ups_sy = (float)Hs / (float)H; a.ups_sx = (float)Ws / (float)W;
+        return launch_conv<3, 8, 2, 2>(a, N, s);
     }
     // Measured on MI355X and NOT adopted (kept out of the build): 16-row tiles (4 rows per wave) -3..5 %;
     // CK=4 with 3 workgroups per CU +-5 % by shape; staggering the two co-resident workgroups by half a
@@ -458,4 +491,14 @@ extern "C" int vfi_conv2d_upsample2x(const float *x_lowres, long long x_bstride,
                                      long long workspace_floats, vfi_stream_t stream) {
     return conv2d_impl(x_lowres, x_bstride, packed_w, bias, residual, res_bstride, y, y_bstride, N, Cin, H, W, Cout, KS,
                        pad_mode, act, true, workspace, workspace_floats, stream);
+}
+
+extern "C" int vfi_conv2d_resized_prefix(const float *x, long long x_bstride, const float *x2, long long x2_bstride,
+                                         int prefix_channels, int Hs, int Ws, const float *packed_w, const float *bias,
+                                         float *y, long long y_bstride, int N, int Cin, int H, int W, int Cout, int KS,
+                                         int pad_mode, int act, float *workspace, long long workspace_floats,
+                                         vfi_stream_t stream) {
+    VFI_REQUIRE(x2, VFI_ERR_INVALID_ARG, "vfi_conv2d_resized_prefix: null x2");
+    return conv2d_impl(x, x_bstride, packed_w, bias, nullptr, 0, y, y_bstride, N, Cin, H, W, Cout, KS, pad_mode, act, false,
+                       workspace, workspace_floats, stream, x2, x2_bstride, prefix_channels, Hs, Ws);
 }

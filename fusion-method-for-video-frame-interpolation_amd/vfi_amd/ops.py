@@ -109,6 +109,27 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2
     return out
 
 
+def conv2d_resized_prefix(x, x2, pc, pad_mode="reflect", act=None, out=None):
+    """conv over [bilinear_resize(x2, align_corners=False) | x[:, C2:]] with C2 = x2.shape[1]; x is (N, Cin, H, W) whose
+    first C2 channels are ignored (never written).  One launch, the resized maps are not materialised."""
+    n, cin, h, w = x.shape
+    n2, c2, hs, ws_ = x2.shape
+    if cin != pc.cin or n2 != n:
+        raise VfiLibraryError("conv2d_resized_prefix: shape mismatch")
+    if out is None:
+        out = new((n, pc.cout, h, w), x)
+    xp, xs = _slice_ptr(x, "x")
+    x2p, x2s = _slice_ptr(x2, "x2")
+    yp, ys = _slice_ptr(out, "out")
+    ws = _workspace(x.device)
+    work = None
+    if _lib.PROFILE is not None:
+        work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w, f"conv2d_mfma_kernel<{pc.ks},8,2,rsz>")
+    _lib.call("vfi_conv2d_resized_prefix", xp, xs, x2p, x2s, c2, hs, ws_, pc.packed.data_ptr(), pc.bias.data_ptr(), yp, ys,
+              n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], ws.data_ptr(), ws.numel(), _lib.stream_ptr(), work=work)
+    return out
+
+
 def adacof_prepare(frame0, frame2, rgbx=True):
     """-> (pad0, pad2, x6 (N,6,Hp,Wp)); Hp, Wp = sizes rounded up to multiples of 32.  pad0/pad2 are the
     reflect-padded raw frames: pixel-interleaved (N,Hp,Wp,4) when rgbx, else planar (N,3,Hp,Wp)."""

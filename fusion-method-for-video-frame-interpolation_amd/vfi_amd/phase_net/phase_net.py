@@ -137,10 +137,13 @@ class PhaseNet(PackedModule):
         b, _, hl, wl = low_in.shape
         stream = _lib.stream_ptr()
 
-        def block(i, x, fp):
+        def block(i, x, fp, prev=None):
             c1, c2, cp = packed[i]
             mode = "reflect" if c1.ks == 3 else "zeros"
-            t = ops.conv2d(x, c1, mode, "elu")
+            if prev is not None:     # 3x3 block: the resize of (feature | prediction) is done by the conv's tile loader
+                t = ops.conv2d_resized_prefix(x, prev, c1, mode, "elu")
+            else:
+                t = ops.conv2d(x, c1, mode, "elu")
             ops.conv2d(t, c2, mode, "elu", out=fp[:, :64])
             ops.conv2d(fp[:, :64], cp, "zeros", "tanh", out=fp[:, 64:])
             return fp
@@ -164,9 +167,11 @@ class PhaseNet(PackedModule):
                 x = ops.new((b, 64 + p_prev + 2 * c, h, w), low_in)
                 ops.affine_slice(ph.contiguous(), x[:, 64 + p_prev:64 + p_prev + c])
                 ops.affine_slice(am.contiguous(), x[:, 64 + p_prev + c:])
-            ops.resize_bilinear(fp, (h, w), align_corners=False, out=x[:, :64 + p_prev])   # :138-141
             i = idx + 1 if idx + 1 < len(self.layers) - 1 else len(self.layers) - 1        # :148
-            fp = block(i, x, ops.new((b, 72, h, w), low_in))
+            fused = packed[i][0].ks == 3 and (64 + p_prev) % 8 == 0
+            if not fused:
+                ops.resize_bilinear(fp, (h, w), align_corners=False, out=x[:, :64 + p_prev])   # :138-141
+            fp = block(i, x, ops.new((b, 72, h, w), low_in), prev=fp if fused else None)
             amp_in = x[:, 64 + p_prev + c:]
             p_out, a_out = ops.new((b * 4, 1, h, w), low_in), ops.new((b * 4, 1, h, w), low_in)
             _lib.call("vfi_phasenet_emit", fp[:, 64:].data_ptr(), fp.stride(0), amp_in.data_ptr(), x.stride(0),

@@ -143,6 +143,18 @@ int vfi_conv2d_upsample2x(const float *x_lowres, long long x_bstride, const floa
                           int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, float *workspace,
                           long long workspace_floats, vfi_stream_t stream);
 
+/* conv2d over the virtual concat [ resize(x2) | x[:, prefix_channels:] ]: the first prefix_channels input channels
+ * are torch's bilinear resize (align_corners=False) of x2 (N, prefix_channels, Hs, Ws) to (H, W), the remaining
+ * Cin - prefix_channels channels are read from x (N, Cin, H, W) -- whose first prefix_channels channels are never
+ * touched.  This is PhaseNet's block input `cat(Upsample(feature), phase, amp, Upsample(prediction))`
+ * (src/phase_net/phase_net.py:138-141, channels permuted at pack time) without writing the resized maps.
+ * KS = 3, Cout % 64 == 0, prefix_channels % 8 == 0. */
+int vfi_conv2d_resized_prefix(const float *x, long long x_bstride, const float *x2, long long x2_bstride,
+                              int prefix_channels, int Hs, int Ws, const float *packed_w, const float *bias,
+                              float *y, long long y_bstride, int N, int Cin, int H, int W, int Cout, int KS,
+                              int pad_mode, int act, float *workspace, long long workspace_floats,
+                              vfi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Glue between the convolutions (HBM-bound; batch strides as for vfi_conv2d)
  * ---------------------------------------------------------------------------------- */

@@ -127,3 +127,20 @@ def test_conv_fused_upsample_matches_torch(n, cin, cout, hs, ws, act, device):
     pc = ops.PackedConv(wgt, b, device=device)
     out = ops.conv2d(x.to(device), pc, "zeros", act, residual=res.to(device), upsample2x=True)
     assert (out.cpu() - ref).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize("n,c2,cd,hs,ws,h,w", [(3, 72, 16, 17, 24, 24, 34), (1, 72, 16, 9, 15, 12, 22), (2, 64, 24, 20, 30, 29, 43)])
+def test_conv_resized_prefix_matches_torch(n, c2, cd, hs, ws, h, w, device):
+    # conv over [bilinear_resize(x2, align_corners=False) | x[:, c2:]] == PhaseNet's block input (phase_net.py:138-141)
+    g = torch.Generator().manual_seed(h * w)
+    x2 = torch.randn((n, c2, hs, ws), generator=g)
+    direct = torch.randn((n, cd, h, w), generator=g)
+    wgt = torch.randn((64, c2 + cd, 3, 3), generator=g) / ((c2 + cd) * 9) ** 0.5
+    b = torch.randn((64,), generator=g) * 0.1
+    full = torch.cat((F.interpolate(x2, size=(h, w), mode="bilinear", align_corners=False), direct), 1)
+    ref = _ref(full, wgt, b, 3, "reflect", "elu")
+    x = torch.full((n, c2 + cd, h, w), float("nan"))            # the prefix channels of x must never be read
+    x[:, c2:] = direct
+    pc = ops.PackedConv(wgt, b, device=device)
+    out = ops.conv2d_resized_prefix(x.to(device), x2.to(device), pc, "reflect", "elu")
+    assert (out.cpu() - ref).abs().max().item() <= 3e-5

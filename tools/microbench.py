@@ -77,6 +77,40 @@ def main():
                 print(f"{name:34s} {t:7.3f} ms")
         print("total", tot)
         _lib.PROFILE = None
+    if args.what == "phasenet":
+        import math, types
+        from vfi_amd import _lib
+        from vfi_amd.phase_net.phase_net import PhaseNet
+        from vfi_amd.train.pyramid import Pyramid
+        pyr = Pyramid(17, 4, math.sqrt(2), dev)
+        net = PhaseNet(pyr, dev)
+        img = torch.rand((6, 1080, 1920), device=dev)
+        def run():
+            vals, bufs = pyr.filter(img, concat_frames=2, phase_scale=1.0 / math.pi)
+            return net(net.normalize_vals(vals, concat=bufs))
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        _lib.PROFILE = _lib.Recorder()
+        run()
+        torch.cuda.synchronize()
+        import collections
+        agg = collections.OrderedDict()
+        tot = 0.0
+        for name, work, e0, e1 in _lib.PROFILE.rows:
+            t = e0.elapsed_time(e1)
+            tot += t
+            key = work[2] if work else name
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += t; a[2] += work[1] if work and work[0] == "flop" else 0.0
+        for k, (c, t, f) in agg.items():
+            print(f"{k:34s} calls {c:3d} {t:8.3f} ms" + (f" {f/t/1e9:7.1f} TF/s" if f else ""))
+        print("total", tot)
+        # per-level conv times
+        lv = [(n, w, e0.elapsed_time(e1)) for n, w, e0, e1 in _lib.PROFILE.rows if w and w[0] == "flop"]
+        for i in range(0, len(lv), 3):
+            print("block", i // 3, " ".join(f"{t:.3f}ms/{w[1]/t/1e9:.0f}TF" for _, w, t in lv[i:i + 3]))
+        _lib.PROFILE = None
     if args.what == "adacof":
         bench_adacof(dev)
     if args.what == "median":
