@@ -1,5 +1,6 @@
 """GPU parity of the three networks (host mirrors over the C ABI) against the fixtures produced by the
 reference's own classes, and against the oracle at a second size."""
+import math
 import os
 import types
 
@@ -114,3 +115,32 @@ def test_phasenet_partial_levels_and_protocol(device):
         net(dv)                               # normalize_vals must come first
     out = net(net.normalize_vals(dv), m=2)    # hierarchical `m` of phase_net.py:107-110,91-93
     assert out.phase[0] == 0 and out.phase[1] == 0 and torch.is_tensor(out.phase[2])
+
+
+def test_architecture_phasenet_image_in_image_out(device):
+    # reference src/phase_net/architecture.py surface: (prediction, vals_pred, vals_target) from Lab channel-images
+    from oracle import pyramid_cpu
+    from vfi_amd.phase_net.architecture import PhaseNet as ArchPhaseNet
+    h, w = 64, 96
+    height = layout_cpu.calc_pyr_height(h, w)
+    f0, _, f2 = synth.translating_pair(4, h, w)
+    img = torch.from_numpy(np.concatenate([f0, f2], 0))                         # 6 channel-images
+    sd = nets_cpu.phasenet_random_state_dict(1)
+    # oracle: pyramid -> layout -> PhaseNet -> inverse pyramid
+    opyr = pyramid_cpu.Pyramid(height)
+    vin = layout_cpu.get_concat_layers_inf(layout_cpu.separate_vals(opyr.filter(img), 2))
+    normed, state = nets_cpu.phasenet_normalize(vin)
+    with torch.no_grad():
+        ref = opyr.inv_filter(nets_cpu.phasenet_forward(sd, normed, state, height))
+    net = ArchPhaseNet(height, device, num_img=2, scale_factor=math.sqrt(2), nbands=4)
+    net.core.load_state_dict(sd)
+    pred, vals_pred, target = net(img.to(device))
+    assert target is None and pred.shape == (3, h, w) and len(vals_pred.phase) == height - 2
+    assert (pred.cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    # hierarchical form: 3 frames (2 inputs + target), m levels predicted, the finest ones taken from the target
+    img3 = torch.cat((img, torch.from_numpy(synth.translating_pair(4, h, w)[1])), 0)
+    pred_m, vals_m, tgt = net(img3.to(device), m=2)
+    assert pred_m.shape == (3, h, w) and tgt is not None and torch.isfinite(pred_m).all()
+    # high_level=True copies the high residual of another prediction in
+    pred_h, vals_h, _ = net(img.to(device), high_level=True, ada_pred=img[:3].to(device))
+    assert vals_h.high_level.abs().max().item() > 0 and torch.isfinite(pred_h).all()
