@@ -263,6 +263,97 @@ __global__ __launch_bounds__(256) void median_rank_kernel(const float *__restric
     }
 }
 
+// ---- quality scoring (reference src/evaluation/evaluate_image.py:7-30) ---------------------------------------------
+// Deterministic two-stage reductions: per-block partial sums in double, then one block adds them in fixed order.
+constexpr int kRedBlocks = 1024;
+__global__ __launch_bounds__(256) void diff_stats_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                 long long n, double *__restrict__ part) {
+    double s1 = 0.0, s2 = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double d = (double)a[i] - (double)b[i];
+        s1 += d; s2 += d * d;
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0][0]; part[2 * blockIdx.x + 1] = sh[1][0]; }
+}
+// SSIM map of piq.ssim (Gaussian-filtered moments in, sum of the per-pixel SSIM over the valid interior out):
+//   cs = (2 sxy + c2) / (sxx + syy + c2) ; ssim = (2 mx my + c1) / (mx^2 + my^2 + c1) * cs ; s** = E[.] - mu products
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const float *__restrict__ mx, const float *__restrict__ my,
+                                                           const float *__restrict__ exx, const float *__restrict__ eyy,
+                                                           const float *__restrict__ exy, int planes, int H, int W, int border,
+                                                           float c1, float c2, double *__restrict__ part) {
+    const int Hv = H - 2 * border, Wv = W - 2 * border;
+    const long long n = (long long)planes * Hv * Wv;
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = i % Wv, y = (i / Wv) % Hv, p = i / ((long long)Wv * Hv);
+        const size_t o = ((size_t)p * H + y + border) * W + x + border;
+        const float a = mx[o], b = my[o];
+        const float sxx = exx[o] - a * a, syy = eyy[o] - b * b, sxy = exy[o] - a * b;
+        const float cs = (2.0f * sxy + c2) / (sxx + syy + c2);
+        s += (double)((2.0f * a * b + c1) / (a * a + b * b + c1) * cs);
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0]; part[2 * blockIdx.x + 1] = 0.0; }
+}
+__global__ void sum_partials_kernel(const double *__restrict__ part, int nblocks, double *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < nblocks; ++i) { s1 += part[2 * i]; s2 += part[2 * i + 1]; }
+        out[0] = s1; out[1] = s2;
+    }
+}
+__global__ void mul_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a[i] * b[i];
+}
+
+}  // namespace
+
+extern "C" int vfi_diff_sums(const float *a, const float *b, long long count, double *out2, void *workspace, vfi_stream_t stream) {
+    VFI_REQUIRE(a && b && out2 && workspace, VFI_ERR_INVALID_ARG, "vfi_diff_sums: null pointer");
+    VFI_REQUIRE(count > 0, VFI_ERR_INVALID_ARG, "vfi_diff_sums: bad size");
+    hipStream_t s = vfi::as_stream(stream);
+    const int nb = (int)((count + 255) / 256 < kRedBlocks ? (count + 255) / 256 : kRedBlocks);
+    hipLaunchKernelGGL(diff_stats_partial_kernel, dim3(nb), dim3(256), 0, s, a, b, count, static_cast<double *>(workspace));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, static_cast<const double *>(workspace), nb, out2);
+    return vfi::check_launch("vfi_diff_sums");
+}
+
+extern "C" int vfi_ssim_sum(const float *mu_x, const float *mu_y, const float *e_xx, const float *e_yy, const float *e_xy,
+                            int planes, int H, int W, int border, float c1, float c2, double *out2, void *workspace,
+                            vfi_stream_t stream) {
+    VFI_REQUIRE(mu_x && mu_y && e_xx && e_yy && e_xy && out2 && workspace, VFI_ERR_INVALID_ARG, "vfi_ssim_sum: null pointer");
+    VFI_REQUIRE(planes > 0 && H > 2 * border && W > 2 * border && border >= 0, VFI_ERR_INVALID_ARG, "vfi_ssim_sum: bad sizes");
+    hipStream_t s = vfi::as_stream(stream);
+    const long long n = (long long)planes * (H - 2 * border) * (W - 2 * border);
+    const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+    hipLaunchKernelGGL(ssim_partial_kernel, dim3(nb), dim3(256), 0, s, mu_x, mu_y, e_xx, e_yy, e_xy, planes, H, W, border, c1, c2,
+                       static_cast<double *>(workspace));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, static_cast<const double *>(workspace), nb, out2);
+    return vfi::check_launch("vfi_ssim_sum");
+}
+
+extern "C" int vfi_mul(const float *a, const float *b, float *out, long long count, vfi_stream_t stream) {
+    VFI_REQUIRE(a && b && out, VFI_ERR_INVALID_ARG, "vfi_mul: null pointer");
+    VFI_REQUIRE(count > 0, VFI_ERR_INVALID_ARG, "vfi_mul: bad size");
+    hipLaunchKernelGGL(mul_kernel, dim3(blocks_1d(count)), dim3(256), 0, vfi::as_stream(stream), a, b, out, count);
+    return vfi::check_launch("vfi_mul");
+}
+
+namespace {
 }  // namespace
 
 extern "C" int vfi_rgb2lab(const float *rgb, float *lab, int N, int HW, vfi_stream_t stream) {

@@ -44,6 +44,9 @@ SIGNATURES = {
     "vfi_absdiff": [c_f, c_f, c_f, c_l, c_fl, c_i, c_s],
     "vfi_gaussian_filter": [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_s],
     "vfi_median_filter": [c_f, c_f, c_i, c_i, c_i, c_i, c_s],
+    "vfi_diff_sums": [c_f, c_f, c_l, c_f, c_f, c_s],
+    "vfi_ssim_sum": [c_f] * 5 + [c_i] * 4 + [c_fl, c_fl, c_f, c_f, c_s],
+    "vfi_mul": [c_f, c_f, c_f, c_l, c_s],
     "vfi_pyr_plan_create": [c_i, c_i, c_i, c_i, c_d, c_i, ctypes.POINTER(ctypes.c_void_p)],
     "vfi_pyr_plan_destroy": [ctypes.c_void_p],
     "vfi_pyr_plan_level_size": [ctypes.c_void_p, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i)],

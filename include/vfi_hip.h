@@ -306,6 +306,24 @@ int vfi_gaussian_filter(const float *x, float *tmp, float *y, int N, int H, int 
  * size=50).  Exact selection (returns an element of the window). */
 int vfi_median_filter(const float *x, float *y, int N, int H, int W, int size, vfi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Quality scoring on device (src/evaluation/evaluate_image.py:7-30)
+ * ---------------------------------------------------------------------------------- */
+
+/* out2[0] = sum(a - b), out2[1] = sum((a - b)^2) over `count` floats, accumulated in double in a fixed order
+ * (deterministic).  PSNR / SSD / L1 / MSE / variance of evaluate_image.py:22-28 follow from the two sums.
+ * workspace: 2 * 1024 doubles. */
+int vfi_diff_sums(const float *a, const float *b, long long count, double *out2, void *workspace, vfi_stream_t stream);
+
+/* Sum of the SSIM map (piq.ssim formula) over the interior [border, H-border) x [border, W-border) of `planes`
+ * planes, from the Gaussian-filtered moments mu_x, mu_y, E[xx], E[yy], E[xy]; out2[0] = sum.  workspace as above. */
+int vfi_ssim_sum(const float *mu_x, const float *mu_y, const float *e_xx, const float *e_yy, const float *e_xy,
+                 int planes, int H, int W, int border, float c1, float c2, double *out2, void *workspace,
+                 vfi_stream_t stream);
+
+/* out = a * b elementwise. */
+int vfi_mul(const float *a, const float *b, float *out, long long count, vfi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
