@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight per GPU (independent frames of the clip on separate HIP streams)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: capture each in-flight frame's ~700 launches into a hipGraph (torch.cuda.CUDAGraph) and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -132,6 +134,32 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    if args.graph:
+        # every library call only enqueues on the given stream (no allocation / synchronisation), so a whole frame can
+        # be captured once per in-flight slot and replayed; inputs are copied into the captured buffers
+        slots = []
+        for k, r in enumerate(runners):
+            f0s, f2s = torch.empty_like(pairs[0][0]), torch.empty_like(pairs[0][1])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(streams[k]):
+                f0s.copy_(pairs[0][0]); f2s.copy_(pairs[0][1])
+                streams[k].synchronize()
+                with torch.cuda.graph(g, stream=streams[k]):
+                    out = r(f0s, f2s, output_baseline=True)["final"]
+            slots.append((g, f0s, f2s, out))
+        eager_step = step
+
+        def step(i):                                         # noqa: F811
+            f0, f2 = pairs[i % len(pairs)]
+            k = i % len(slots)
+            g, f0s, f2s, out = slots[k]
+            with torch.cuda.stream(streams[k]):
+                f0s.copy_(f0, non_blocking=True); f2s.copy_(f2, non_blocking=True)
+                g.replay()
+            return out
+        for i in range(2):
+            step(i)
+        barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -148,17 +176,19 @@ def main():
                                        f"at {w}x{h}, BASELINE.json configs[3]; one frame pair per rank per step",
                            "frame": [h, w], "weights": f"random-init, {n_weights} params broadcast from rank 0",
                            "sharding": f"frame pairs over {world} rank(s), no data-path collective",
-                           "frames_in_flight_per_gpu": args.streams}}
+                           "frames_in_flight_per_gpu": args.streams, "hip_graph": bool(args.graph)}}
         if not args.no_profile:
             # Per-kernel algorithmic work / measured duration (HIP events on the launch stream of each call).
             #  * "roofline": measured in the SAME regime as the timed region (one frame per stream, S frames in
             #    flight), so its average launch duration is the one rocprofv3 --stats reports for this command;
             #  * "roofline_isolated": one frame alone on the device (kernel quality without sharing the chip).
+            prof_step = eager_step if args.graph else step
+
             def profile(n_frames):
                 torch.cuda.synchronize()
                 _lib.PROFILE = _lib.Recorder()
                 for i in range(n_frames):
-                    step(i)
+                    prof_step(i)
                 agg = _lib.PROFILE.summary()
                 _lib.PROFILE = None
                 return agg

@@ -81,3 +81,29 @@ def test_fused_frame_full_size_properties(h, w, device):
     # frame order symmetry of the sampler's mask: swapping the inputs swaps the two sampling sides
     m1 = run(f0, f2)["flow_var_map"]
     assert m1.shape == (1, 1, h, w)
+
+
+def test_frame_is_capturable_into_a_hip_graph(device):
+    # every library call only enqueues on its stream (no allocation / synchronisation inside): a whole frame,
+    # hipFFT included, can be captured into a hipGraph and replayed on new inputs with identical results
+    weights = pipeline_cpu.seeded_weights(3)
+    run = _models(device, weights)
+    a0, _, a2 = (torch.from_numpy(x).to(device) for x in synth.translating_pair(5, 64, 96))
+    b0, _, b2 = (torch.from_numpy(x).to(device) for x in synth.translating_pair(6, 64, 96))
+    want_a = run(a0, a2)["final"].clone()          # also warms up plans / packed weights
+    want_b = run(b0, b2)["final"].clone()
+    s = torch.cuda.Stream(device=device)
+    f0, f2 = torch.empty_like(a0), torch.empty_like(a2)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        f0.copy_(a0); f2.copy_(a2)
+        s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            out = run(f0, f2)["final"]
+        g.replay()
+        s.synchronize()
+        assert torch.equal(out, want_a)
+        f0.copy_(b0); f2.copy_(b2)
+        g.replay()
+        s.synchronize()
+        assert torch.equal(out, want_b)
