@@ -51,15 +51,24 @@ def _decode(path, dim=None):
     return torch.from_numpy(np.ascontiguousarray(img))          # (H,W,3) uint8
 
 
-def _encode(arr_hwc_u8, path):
+def _encode(arr_hwc_u8, path, event=None):
     from PIL import Image
-    Image.fromarray(arr_hwc_u8).save(path)
+    if event is not None:
+        event.synchronize()                 # the D2H copy of this frame (enqueued on its compute stream) has landed
+    if torch.is_tensor(arr_hwc_u8):
+        arr_hwc_u8 = arr_hwc_u8.numpy()
+    Image.fromarray(arr_hwc_u8).save(path, compress_level=1)    # same pixels as the default level, ~4x faster
 
 
-def _to_u8_host(t):
-    """(3,H,W) float in [0,1] on device -> (H,W,3) uint8 numpy, torchvision.save_image quantisation."""
-    q = t.detach().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)
-    return q.cpu().numpy()
+def _quantise_to_host(t):
+    """(3,H,W) float in [0,1] on device -> (H,W,3) uint8 pinned host tensor (torchvision.save_image quantisation),
+    enqueued on the current stream; returns (host tensor, event to wait for)."""
+    q = t.detach().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).contiguous()
+    host = torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+    host.copy_(q, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev
 
 
 def interpolate_video(args, runners=None, loaded_adacof_model=None, loaded_fusion_net=None, frames_in_flight=2,
@@ -98,8 +107,7 @@ def interpolate_video(args, runners=None, loaded_adacof_model=None, loaded_fusio
     for i in range(lo, min(hi, lo + 2 * len(runners)) + 1):
         want(i)
     writes, written = [], 0
-    prev = None                       # (index, device tensor) of the pair's first frame, reused as the next pair's
-    pending = []                      # (stream event, interpolated tensor, first-frame host array, pair index)
+    prev = None                       # (index, device tensor, upload event) of the pair's second frame
     for k, i in enumerate(range(lo, hi)):
         want(i + 2 * len(runners))
         want(i + 2 * len(runners) + 1)
@@ -115,26 +123,17 @@ def interpolate_video(args, runners=None, loaded_adacof_model=None, loaded_fusio
             up_ev = torch.cuda.Event()
             up_ev.record(s)                      # the next pair waits for this upload only, not for this pair's compute
             out = runners[k % len(runners)](f0, f1)["final"][0]
-            ev = torch.cuda.Event()
-            ev.record(s)
+            host, ev = _quantise_to_host(out)    # D2H on the same stream; a pool thread waits for it and encodes
         prev = (i + 1, f1, up_ev)
-        pending.append((ev, out, decoded[i].result().numpy(), i - 0))
-        decoded.pop(i - 1, None)
-        while len(pending) > len(runners):
-            ev0, out0, first0, pi = pending.pop(0)
-            ev0.synchronize()
-            a, b = output_indices(pi, index_from)
-            writes.append(pool.submit(_encode, first0, frame_path(out_dir, a, zpad)))
-            writes.append(pool.submit(_encode, _to_u8_host(out0), frame_path(out_dir, b, zpad)))
-            written += 1
-    for ev0, out0, first0, pi in pending:
-        ev0.synchronize()
-        a, b = output_indices(pi, index_from)
-        writes.append(pool.submit(_encode, first0, frame_path(out_dir, a, zpad)))
-        writes.append(pool.submit(_encode, _to_u8_host(out0), frame_path(out_dir, b, zpad)))
+        a, b = output_indices(i, index_from)
+        writes.append(pool.submit(_encode, decoded[i].result(), frame_path(out_dir, a, zpad)))
+        writes.append(pool.submit(_encode, host, frame_path(out_dir, b, zpad), ev))
         written += 1
+        decoded.pop(i - 1, None)
+        while len(writes) > 8 * len(runners):    # bound the pinned buffers / queued encodes
+            writes.pop(0).result()
     if hi == n_frames - 1 and n_frames > 0:      # last original frame (interpolate_video.py:116-119), by its owner rank
-        last = decoded[hi].result().numpy() if hi in decoded else _decode(frame_path(base, hi + index_from, zpad), dim).numpy()
+        last = decoded[hi].result() if hi in decoded else _decode(frame_path(base, hi + index_from, zpad), dim)
         writes.append(pool.submit(_encode, last, frame_path(out_dir, (n_frames - 1) * 2 + index_from, zpad)))
     for w in writes:
         w.result()

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""PNG-inclusive clip rate at 1080p (decode + H2D + interpolate + D2H + encode) for the note in DESIGN.md section 6."""
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "fusion-method-for-video-frame-interpolation_amd")]
+import bench  # noqa: E402
+from vfi_amd.fusion_net import interpolate_video as iv  # noqa: E402
+from PIL import Image  # noqa: E402
+
+dev = torch.device("cuda:0")
+runners, _ = bench.build_runner(dev, 2)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
+with tempfile.TemporaryDirectory() as td:
+    src, dst = os.path.join(td, "in"), os.path.join(td, "out")
+    os.makedirs(src)
+    pairs = bench.synthetic_pairs(1, 1080, 1920, dev)
+    base = (pairs[0][0].permute(1, 2, 0) * 255).byte().cpu().numpy()
+    for i in range(n):
+        Image.fromarray(np.roll(base, 3 * i, axis=1)).save(os.path.join(src, f"{i:03d}.png"))
+    args = types.SimpleNamespace(gpu_id=0, input_video=src, output_video=dst, index_from=0, zpad=3)
+    iv.interpolate_video(args, runners=runners, io_threads=8)          # warm-up (plans, packed weights)
+    for f in os.listdir(dst):
+        os.remove(os.path.join(dst, f))
+    t0 = time.perf_counter()
+    done = iv.interpolate_video(args, runners=runners, io_threads=8)
+    dt = time.perf_counter() - t0
+    print(f"clip of {n} frames at 1920x1080 from/to PNG: {done} interpolated frames in {dt:.2f} s = {done/dt:.2f} frames/s "
+          f"(8 I/O threads, 2 frames in flight)")
