@@ -140,7 +140,7 @@ def test_fused_rgbx_equals_planar(device):
     got = adacof_fused(inter(d["f0"]), inter(d["f2"]), d["w1"], d["a1"], d["b1"], d["w2"], d["a2"], d["b2"], d["occ"], 1,
                        rgbx=True)
     for a, b in zip(ref, got):
-        assert (a - b).abs().max().item() <= 1e-6
+        assert (a - b).abs().max().item() <= 5e-6
     # softmax folded into the sampler: logits in, same outputs
     lg1 = torch.log(d["w1"]) + 3.0 + torch.randn(2, 1, 40, 72, device=device) * 20.0   # shifts cancel in softmax
     lg2 = torch.log(d["w2"]) - 50.0
