@@ -473,6 +473,7 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     // CK=4 with 3 workgroups per CU +-5 % by shape; staggering the two co-resident workgroups by half a
     // workgroup: no change; a persistent tile loop (512 resident workgroups walking the tiles, next tile's first
     // chunk requested before the epilogue): -8 % (per-tile setup + spills outweigh the saved dispatch gaps).
+    // Pseudo-random within-chunk start offsets for the first-round workgroups (de-phasing chunk boundaries): 0 %.
     // MFMA pipe utilisation of this structure is 70-76 % (PMC) at ~2.18 GHz.
     if (KS == 3) return wide ? launch_conv<3, 8, 2>(a, N, s) : launch_conv<3, 8, 1>(a, N, s);
     if (KS == 5) return wide ? launch_conv<5, 4, 2>(a, N, s) : launch_conv<5, 4, 1>(a, N, s);
