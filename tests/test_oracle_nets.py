@@ -132,3 +132,50 @@ def test_trained_checkpoints_load_into_oracle_key_layout():
     want = dict(nets_cpu.fusionnet_shapes())
     assert set(sd) == set(want)
     assert all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "src/phase_net/phase_net.pt")),
+                    reason="the reference (and its trained checkpoints) only exist in the build container")
+def test_oracle_matches_reference_classes_with_trained_weights():
+    # Build-container only: the reference's OWN classes with its OWN trained checkpoints (read as data, never
+    # committed) against the oracle restatements on seeded inputs -- realistic BatchNorm statistics / weight scales.
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg._placeholders()
+    from src.fusion_net.fusion_net import FusionNet as RefFusion
+    from src.phase_net.phase_net import PhaseNet as RefPhaseNet
+    from src.train import utils as rutils
+    from src.train.pyramid import DecompValues as RefVals
+    # PhaseNet
+    sd = torch.load(os.path.join(REF, "src/phase_net/phase_net.pt"), map_location="cpu")
+    h, w = 48, 64
+    height = layout_cpu.calc_pyr_height(h, w)
+    pyr = types.SimpleNamespace(height=height, nbands=4)
+    ref = RefPhaseNet(pyr, torch.device("cpu"), num_img=2)
+    ref.load_state_dict(sd)
+    ref.eval()
+    batch = synth.synthetic_vals(11, 6, h, w, height)
+    vin_ref = rutils.get_concat_layers_inf(pyr, rutils.separate_vals(RefVals(*batch), 2))
+    with torch.no_grad():
+        want = ref(ref.normalize_vals(vin_ref))
+    vin = layout_cpu.get_concat_layers_inf(layout_cpu.separate_vals(batch, 2))
+    normed, state = nets_cpu.phasenet_normalize(vin)
+    with torch.no_grad():
+        got = nets_cpu.phasenet_forward(sd, normed, state, height)
+    for a, b in zip(got.phase + got.amplitude + [got.low_level], want.phase + want.amplitude + [want.low_level]):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    # FusionNet
+    sd = torch.load(os.path.join(REF, "src/fusion_net/fusion_net.pt"), map_location="cpu")
+    ref = RefFusion()
+    ref.load_state_dict(sd)
+    ref.eval()
+    g = torch.Generator().manual_seed(5)
+    r = lambda c: torch.rand((1, c, 40, 56), generator=g)
+    base, ada, ph, other, maps = r(3), r(3), r(3), r(6), r(3)
+    with torch.no_grad():
+        want = ref(base, ada, ph, other, maps, variant=0)
+        got = nets_cpu.fusionnet_forward(sd, base, ada, ph, other, maps, 0)
+    assert (got - want).abs().max().item() <= 1e-6
