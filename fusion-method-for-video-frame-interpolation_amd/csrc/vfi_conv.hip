@@ -24,54 +24,23 @@
 //   * bias, activation (ReLU / ELU / tanh / sigmoid) and an optional residual add are fused into
 //     the epilogue; batch strides are explicit so inputs / outputs may be channel slices of larger
 //     (concatenated) tensors without a copy.
-#include "vfi_common.h"
+#include "vfi_conv_common.h"
 
 #include <cstdlib>
+
+using namespace vfi::conv;
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-struct ConvArgs {
-    const float *x;      // (N, Cin, H, W) slice, batch stride x_bs
-    const float *wp;     // packed weights [Cin_pad][KS*KS][Cout_pad]
-    const float *bias;   // (Cout) or null
-    const float *res;    // residual (N, Cout, H, W) slice, batch stride res_bs, or null
-    float *y;            // (N, Cout, H, W) slice, batch stride y_bs
-    long long x_bs, res_bs, y_bs;
-    int Cin, Cin_pad, Cout, Cout_pad, H, W, tiles_x;
-    int pad_mode;  // 0 zero, 1 reflect
-    int act;       // vfi_act
-    long long ws_floats;
-    float *ws;     // split-K partial sums [splits][N][Cout][H][W] (splits > 1)
-    int splits;    // K (input-channel chunk) range split over `splits` workgroups per output tile
-    const float *x2;       // SRC = 2: tensor whose resize forms the first rsz_channels input channels
-    long long x2_bs;
-    int rsz_channels;      // multiple of CK
-    int Hs, Ws;    // UPS kernels: size of the low-resolution source x (H = 2*Hs, W = 2*Ws)
-    float ups_sy, ups_sx;   // (Hs-1)/(H-1), (Ws-1)/(W-1): torch bilinear, align_corners=True
-};
 
 // Padding / channel-tail elements of the input tile are loaded from here instead of being selected to zero
 // after the load: a select would make the loaded value "used" right away and force s_waitcnt vmcnt(0)
 // BEFORE the chunk's MFMAs, i.e. no overlap of the prefetch with compute.
 __device__ float g_zero_word = 0.0f;   // (non-const: stays in the global address space -> global_load, not flat_load)
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case 1: return fmaxf(v, 0.0f);
-        case 2: return v > 0.0f ? v : expm1f(v);
-        case 3: return tanhf(v);
-        case 4: return 1.0f / (1.0f + expf(-v));
-        default: return v;
-    }
-}
 
-__device__ __forceinline__ int reflect_index(int i, int n) {
-    i = i < 0 ? -i : i;
-    i = i >= n ? 2 * (n - 1) - i : i;
-    return min(max(i, 0), n - 1);  // tile overhang beyond the reflected range feeds discarded outputs only
-}
 
 template <int KS, int CK, int NT, int RW = 2>
 struct ConvTile {
@@ -367,7 +336,6 @@ __global__ void conv2d_pack_kernel(const float *__restrict__ w, const float *__r
     }
 }
 
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 template <int KS, int CK, int NT, int UPS = 0, int RW = 2>
 int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
@@ -398,20 +366,23 @@ int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
     }
     dim3 grid(a.tiles_x * tiles_y, a.Cout_pad / T::BN, N * b.splits);
     hipLaunchKernelGGL((conv2d_mfma_kernel<KS, CK, NT, UPS, RW>), grid, dim3(256), T::LDS_BYTES, s, b);
-    if (b.splits > 1) {
-        const long long tot = out_floats;
-        const int rb = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
-        hipLaunchKernelGGL(conv2d_splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, b.ws, b.splits, b.bias, b.res, b.res_bs,
-                           b.y, b.y_bs, N, b.Cout, b.H * b.W, b.act);
-    }
+    if (b.splits > 1) launch_splitk_reduce(b, N, s);
     return vfi::check_launch("vfi_conv2d");
 }
 
 }  // namespace
 
+void vfi::conv::launch_splitk_reduce(const ConvArgs &b, int N, hipStream_t s) {
+    const long long tot = (long long)N * b.Cout * b.H * b.W;
+    const int rb = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    hipLaunchKernelGGL(conv2d_splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, b.ws, b.splits, b.bias, b.res, b.res_bs,
+                       b.y, b.y_bs, N, b.Cout, b.H * b.W, b.act);
+}
+
 extern "C" long long vfi_conv2d_packed_floats(int Cout, int Cin, int KS) {
     if (Cout <= 0 || Cin <= 0 || KS <= 0) return -1;
-    return (long long)round_up(Cin, 8) * KS * KS * round_up(Cout, 32);
+    // 3x3: the direct layout [Cin_pad][9][Cout_pad] is followed by the Winograd layout [Cin_pad][4][Cout_pad][4]
+    return (long long)round_up(Cin, 8) * (KS * KS + (KS == 3 ? 16 : 0)) * round_up(Cout, 32);
 }
 
 extern "C" int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin,
@@ -419,10 +390,12 @@ extern "C" int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *p
     VFI_REQUIRE(w_oihw && packed, VFI_ERR_INVALID_ARG, "vfi_conv2d_pack: null pointer");
     VFI_REQUIRE(Cout > 0 && Cin > 0 && (KS == 1 || KS == 3 || KS == 5), VFI_ERR_INVALID_ARG,
                 "vfi_conv2d_pack: bad shape Cout=%d Cin=%d KS=%d", Cout, Cin, KS);
-    const long long total = vfi_conv2d_packed_floats(Cout, Cin, KS);
+    const int Cin_pad = round_up(Cin, 8), Cout_pad = round_up(Cout, 32);
+    const long long total = (long long)Cin_pad * KS * KS * Cout_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(conv2d_pack_kernel, dim3(blocks), dim3(256), 0, vfi::as_stream(stream), w_oihw, scale,
-                       packed, Cout, Cin, KS * KS, round_up(Cin, 8), round_up(Cout, 32));
+                       packed, Cout, Cin, KS * KS, Cin_pad, Cout_pad);
+    if (KS == 3) launch_pack_winograd(w_oihw, scale, packed + total, Cout, Cin, Cin_pad, Cout_pad, vfi::as_stream(stream));
     return vfi::check_launch("vfi_conv2d_pack");
 }
 
@@ -449,7 +422,7 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     a.H = H; a.W = W; a.tiles_x = vfi::ceil_div(W, 32);
     a.pad_mode = pad_mode; a.act = act;
     a.ws = workspace_floats > 0 ? workspace : nullptr; a.ws_floats = workspace ? workspace_floats : 0; a.splits = 1;
-    a.x2 = nullptr; a.x2_bs = 0; a.rsz_channels = 0;
+    a.x2 = nullptr; a.x2_bs = 0; a.rsz_channels = 0; a.wino_tiles = 0; a.wino_items = 0; a.wino_batch = 0;
     a.Hs = H / 2; a.Ws = W / 2;
     a.ups_sy = H > 1 ? (float)(a.Hs - 1) / (float)(H - 1) : 0.0f;
     a.ups_sx = W > 1 ? (float)(a.Ws - 1) / (float)(W - 1) : 0.0f;
@@ -475,6 +448,13 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     // chunk requested before the epilogue): -8 % (per-tile setup + spills outweigh the saved dispatch gaps).
     // Pseudo-random within-chunk start offsets for the first-round workgroups (de-phasing chunk boundaries): 0 %.
     // MFMA pipe utilisation of this structure is 70-76 % (PMC) at ~2.18 GHz.
+    // 3x3: Winograd F(2x2,3x3) unless VFI_CONV_WINOGRAD=0 (tuning / A-B aid: the direct kernels stay built) or the
+    // sample's input exceeds the 32-bit byte range of a buffer descriptor
+    static const bool wino_on = !(getenv("VFI_CONV_WINOGRAD") && atoi(getenv("VFI_CONV_WINOGRAD")) == 0);
+    if (KS == 3 && wino_on && (long long)Cin * H * W * 4 < (1ll << 32)) {
+        a.wp = packed_w + (size_t)a.Cin_pad * 9 * a.Cout_pad;
+        return launch_winograd(a, N, s);
+    }
     if (KS == 3) return wide ? launch_conv<3, 8, 2>(a, N, s) : launch_conv<3, 8, 1>(a, N, s);
     if (KS == 5) return wide ? launch_conv<5, 4, 2>(a, N, s) : launch_conv<5, 4, 1>(a, N, s);
     return wide ? launch_conv<1, 8, 2>(a, N, s) : launch_conv<1, 8, 1>(a, N, s);

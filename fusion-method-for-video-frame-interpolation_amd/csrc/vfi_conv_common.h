@@ -1,0 +1,56 @@
+// Shared by the two convolution translation units (vfi_conv.hip: direct kernels, pack, entry points;
+// vfi_conv_winograd.hip: the 3x3 Winograd kernel).
+#pragma once
+#include "vfi_common.h"
+
+namespace vfi {
+namespace conv {
+
+struct ConvArgs {
+    const float *x;      // (N, Cin, H, W) slice, batch stride x_bs
+    const float *wp;     // packed weights [Cin_pad][KS*KS][Cout_pad]
+    const float *bias;   // (Cout) or null
+    const float *res;    // residual (N, Cout, H, W) slice, batch stride res_bs, or null
+    float *y;            // (N, Cout, H, W) slice, batch stride y_bs
+    long long x_bs, res_bs, y_bs;
+    int Cin, Cin_pad, Cout, Cout_pad, H, W, tiles_x;
+    int pad_mode;  // 0 zero, 1 reflect
+    int act;       // vfi_act
+    long long ws_floats;
+    float *ws;     // split-K partial sums [splits][N][Cout][H][W] (splits > 1)
+    int splits;    // K (input-channel chunk) range split over `splits` workgroups per output tile
+    const float *x2;       // SRC = 2: tensor whose resize forms the first rsz_channels input channels
+    long long x2_bs;
+    int rsz_channels;      // multiple of CK
+    int wino_tiles, wino_items, wino_batch;   // Winograd kernel: spatial tiles per sample; work items per K split; N
+    int Hs, Ws;    // UPS kernels: size of the low-resolution source x (H = 2*Hs, W = 2*Ws)
+    float ups_sy, ups_sx;   // (Hs-1)/(H-1), (Ws-1)/(W-1): torch bilinear, align_corners=True
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case 1: return fmaxf(v, 0.0f);
+        case 2: return v > 0.0f ? v : expm1f(v);
+        case 3: return tanhf(v);
+        case 4: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ int reflect_index(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return min(max(i, 0), n - 1);  // tile overhang beyond the reflected range feeds discarded outputs only
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// vfi_conv.hip
+void launch_splitk_reduce(const ConvArgs &a, int N, hipStream_t s);
+// vfi_conv_winograd.hip
+int launch_winograd(const ConvArgs &a, int N, hipStream_t s);
+void launch_pack_winograd(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin, int Cin_pad, int Cout_pad,
+                          hipStream_t s);
+
+}  // namespace conv
+}  // namespace vfi

@@ -1,0 +1,423 @@
+// 3x3 convolutions (stride 1, "same" size, zero or reflect padding): Winograd F(2x2, 3x3) on the gfx950 matrix
+// cores, v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).  Same callers as vfi_conv.hip (PhaseNet blocks,
+// KernelEstimation U-Net and heads, FusionNet's 3x3 layers).
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A : 16 multiply-adds per 2x2 outputs and channel pair instead of 36.
+//
+//   * a workgroup (256 threads) works on an 8-row x 32-column output tile (4 x 16 Winograd tiles) for 32 output
+//     channels; wave w owns tile row w.  M = 16 output channels, N = 16 tiles, K = 4 input channels per MFMA; the 16
+//     frequency positions x 2 channel halves are 32 independent accumulators (128 registers) per wave;
+//   * per K step each lane reads ONE raw 4x4 input patch (its tile, its channel: 8-byte LDS reads), forms
+//     V = B^T d B in registers (32 adds) and feeds V's 16 entries to the 16 x 2 MFMAs; the A operands are the
+//     pre-transformed weights U = G g G^T ([cin][row i][cout][column j] in LDS: one ds_read_b128 = four positions);
+//   * the 16 position accumulators of one (channel, tile) sit in one lane: the output transform is register-only;
+//   * staging is all LDS-DMA (buffer_load ... lds): no staging registers, no ds_write pass, no per-chunk address
+//     arithmetic -- per-lane source offsets are tile-invariant, the chunk's channel base and the channel tail live
+//     in the (scalar) buffer descriptor, out-of-range offsets (zero padding, tail channels) read as 0.  Interior tiles
+//     fetch 16 bytes per lane (2 + 2 DMA instructions per wave and 4-channel chunk), tiles on the left / right image
+//     border fetch per element (7 + 2);
+//   * a chunk is only 1024 MFMA cycles per wave, far less than the HBM latency, so the chunks flow through a ring of
+//     NBUF LDS buffers filled NBUF-1 chunks ahead: ONE raw s_barrier per chunk and a COUNTED s_waitcnt vmcnt;
+//   * the fixed cost of a tile (first-chunk latency, 2 x 2 x 8 output rows of stores, workgroup launch) is as long as
+//     ~12 chunks when paid serially, so workgroups are PERSISTENT: 2 per CU walk the (tile, channel block) items,
+//     the ring keeps running across items (the next item's first chunks are requested during the current item's last
+//     MFMAs) and an item's stores drain behind the next item's MFMAs;
+//   * items are ordered so that the workgroups of one XCD (own L2) take the channel blocks of the same spatial tile
+//     back to back: the input tile comes from HBM once, not Cout/32 times.
+#include "vfi_conv_common.h"
+
+using namespace vfi::conv;
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct WinoTile {
+    static constexpr int TH = 8, TW = 32, R = TH + 2, CK = 4, BN = 32;
+    static constexpr int ROWP = 36;                       // LDS row pitch: 34 columns fetched as 9 float4
+    static constexpr int PLANE = R * ROWP;                // 360
+    // LDS stride of a channel plane = 32 (mod 64) dwords: the four channels of a K step (lanes 16k..16k+15 read
+    // channel k) then fall into disjoint bank halves for the 8-byte patch reads
+    static constexpr int PLANE_S = (PLANE - 32 + 63) / 64 * 64 + 32;   // 416
+    static constexpr int PIECES = PLANE_S / 4;            // float4 pieces per plane (104, 90 of them real)
+    static constexpr int IN_X4 = (CK * PIECES + 255) / 256;             // 16-byte DMA instructions per wave (2)
+    static constexpr int IN_X1 = (CK * PLANE_S + 255) / 256;            // 4-byte DMA instructions per wave (7)
+    static constexpr int IN_FLOATS = IN_X4 * 1024;        // 2048 >= IN_X1 * 256
+    static constexpr int W_FLOATS = CK * 16 * BN, W_INSTR = W_FLOATS / 4 / 256;   // 2048 floats, 2 per wave
+    static constexpr int BUF = IN_FLOATS + W_FLOATS;      // 16 KiB
+    static constexpr int NBUF = 4, DIST = NBUF - 1;
+    static constexpr int MIN_LOADS = IN_X4 + W_INSTR;     // fewest DMA instructions a chunk issues per wave
+    static constexpr int BIAS_OFF = NBUF * BUF;          // NBUF x 64 floats: the bias of the items in flight
+    static constexpr size_t LDS_BYTES = ((size_t)NBUF * BUF + NBUF * 64) * sizeof(float);
+    static_assert(IN_X1 * 256 <= IN_FLOATS && PLANE_S % 4 == 0 && ROWP % 4 == 0, "tile layout");
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword data
+}
+
+// The cursors below are wave-uniform by construction, but the compiler cannot always prove it (and then wraps every DMA
+// in a waterfall loop over "divergent" descriptors): pin them to SGPRs.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const char *uni(const char *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+}
+
+// One work item = (K split, sample, spatial tile, 32-channel block).
+struct Item {
+    int split, n, x0, y0, nb;
+    bool valid;
+};
+
+__device__ __forceinline__ Item decode_item(const ConvArgs &a, int L) {
+    using T = WinoTile;
+    Item it;
+    const int cb = a.Cout_pad / T::BN;
+    it.split = L / a.wino_items;
+    const int Lr = L - it.split * a.wino_items;
+    const int tl = (Lr / (8 * cb)) * 8 + (Lr & 7);         // see the header comment: XCD-aware order
+    it.nb = (Lr >> 3) % cb;
+    it.n = tl / a.wino_tiles;
+    const int t = tl - it.n * a.wino_tiles;
+    it.valid = it.n < a.wino_batch;
+    it.x0 = (t % a.tiles_x) * T::TW;
+    it.y0 = (t / a.tiles_x) * T::TH;
+    return it;
+}
+
+// RES: a residual tensor is added after the activation.  Its (ordinary) loads make the compiler drain the DMA ring
+// in every item epilogue, so layers without a residual get an instantiation without them.
+// ACT: the activation as a compile-time constant (-1: read it from the arguments) -- the epilogue applies it to 64 values
+// per lane, and five inlined branches per value are most of the kernel's code size.
+template <bool RES, int ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs a) {
+    using T = WinoTile;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, k4 = lane >> 4;       // lane roles in an MFMA: tile column / channel of the K = 4 step
+    const int HW = a.H * a.W, G = gridDim.x, N = a.wino_batch;
+    const int Ltotal = a.wino_items * a.splits;
+    const int nchunks_all = (a.Cin + T::CK - 1) / T::CK;
+
+    auto next_valid = [&](int L) {      // first valid item at or after L in this workgroup's sequence
+        while (L < Ltotal && !decode_item(a, L).valid) L += G;
+        return L;
+    };
+
+    // ------------------------------------------------------------------------------------------------------------
+    // DMA side ("issue cursor"): item iL, chunk ich of [.., ich_end); per-lane source offsets of the item's tile
+    // ------------------------------------------------------------------------------------------------------------
+    int iL = next_valid(blockIdx.x), ich = 0, ich_end = 0, iseq = -1, inb = 0;
+    bool iborder = false, ifirst = false;
+    unsigned voff[T::IN_X1], woff[T::W_INSTR];
+    const char *ixn = nullptr;
+    auto setup_issue = [&]() {
+        const Item it = decode_item(a, iL);
+        ++iseq;
+        ifirst = true;
+        inb = it.nb;
+        ich = nchunks_all * it.split / a.splits;
+        ich_end = nchunks_all * (it.split + 1) / a.splits;
+        ixn = reinterpret_cast<const char *>(a.x + (size_t)it.n * a.x_bs);
+        iborder = it.x0 == 0 || it.x0 + T::TW >= a.W;      // a fetched 16-byte piece would wrap around an image row
+        if (iborder) {
+#pragma unroll
+            for (int i = 0; i < T::IN_X1; ++i) {
+                const int e = 64 * (wave + 4 * i) + lane;            // LDS dword inside the buffer's input part
+                const int c = e / T::PLANE_S, rem = e % T::PLANE_S, r = rem / T::ROWP, xx = rem % T::ROWP;
+                int gy = it.y0 - 1 + r, gx = it.x0 - 1 + xx;
+                bool ok = c < T::CK && rem < T::PLANE && xx < T::TW + 2;
+                if (a.pad_mode == 1) {
+                    gy = reflect_index(gy, a.H);
+                    gx = reflect_index(gx, a.W);
+                } else {
+                    ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                }
+                voff[i] = ok ? (unsigned)(c * HW + gy * a.W + gx) * 4u : 0xffffffffu;   // out of range -> the DMA writes 0
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < T::IN_X4; ++t) {
+                const int f = 64 * (wave + 4 * t) + lane;            // float4 piece inside the buffer's input part
+                const int c = f / T::PIECES, rem = f % T::PIECES, r = rem / (T::ROWP / 4), q = rem % (T::ROWP / 4);
+                int gy = it.y0 - 1 + r;
+                bool ok = c < T::CK && rem < T::PLANE / 4;
+                if (a.pad_mode == 1) gy = reflect_index(gy, a.H);
+                else ok = ok && gy >= 0 && gy < a.H;
+                voff[t] = ok ? (unsigned)(c * HW + gy * a.W + it.x0 - 1 + 4 * q) * 4u : 0xffffffffu;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T::W_INSTR; ++t) {
+            const int f = 64 * (wave + 4 * t) + lane;            // float4 inside the slab [4 cin][4 i][32 cout][4 j]
+            woff[t] = (unsigned)(((f / T::BN) * a.Cout_pad + it.nb * T::BN + f % T::BN) * 16);
+        }
+    };
+    const char *wn = reinterpret_cast<const char *>(a.wp);
+    const size_t in_chunk_bytes = (size_t)T::CK * HW * 4, w_chunk_bytes = (size_t)T::CK * 4 * a.Cout_pad * 16;
+
+    // Requests the next chunk of this workgroup's item sequence into ring slot `slot` and advances the cursor.  Past
+    // the end it still issues MIN_LOADS (empty) DMA instructions so that the counted wait below stays valid.
+    auto issue_next = [&](int slot) {
+        float *b = lds + uni(slot) * T::BUF;
+        const bool live = uni(iL) < Ltotal;
+        const int uch = uni(ich);
+        const bool border = uni(iborder ? 1 : 0) != 0, first = uni(ifirst ? 1 : 0) != 0;
+        const long long in_left = live ? ((long long)a.Cin - (long long)uch * T::CK) * HW * 4 : 0;   // channel tail -> 0
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(uni(live ? ixn + uch * in_chunk_bytes : wn),
+                                                    (unsigned)uni((int)(unsigned)(in_left > 0xffffffffll ? 0xffffffffll : in_left)));
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(uni(live ? wn + uch * w_chunk_bytes : wn), live ? (unsigned)w_chunk_bytes : 0u);
+        if (live && border) {
+#pragma unroll
+            for (int i = 0; i < T::IN_X1; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(b + 64 * (wave + 4 * i)),
+                                                         4, voff[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < T::IN_X4; ++t)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(b + 256 * (wave + 4 * t)),
+                                                         16, voff[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < T::W_INSTR; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(b + T::IN_FLOATS + 256 * (wave + 4 * t)),
+                                                     16, woff[t], 0, 0, 0);
+        // The item's bias goes through LDS as well: an ordinary load in the epilogue would make the compiler drain
+        // the whole DMA ring (vmcnt(0)) before its first use.  (More DMA instructions only make the counted wait
+        // earlier; a null / short bias reads as 0.)
+        if (live && first && uni(wave) == 0) {
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? a.bias : a.wp, a.bias ? (unsigned)a.Cout * 4u : 0u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(lds + T::BIAS_OFF + (uni(iseq) & (T::NBUF - 1)) * 64),
+                                                     4, lane < T::BN ? (unsigned)(uni(inb) * T::BN + lane) * 4u : 0xffffffffu, 0, 0, 0);
+        }
+        ifirst = false;
+        if (live && ++ich == ich_end) {
+            iL = next_valid(iL + G);
+            if (iL < Ltotal) setup_issue();
+        }
+    };
+    if (iL < Ltotal) setup_issue();
+#pragma unroll
+    for (int p = 0; p < T::DIST; ++p) issue_next(p);
+
+    // ------------------------------------------------------------------------------------------------------------
+    // MFMA side
+    // ------------------------------------------------------------------------------------------------------------
+    const int b_base = k4 * T::PLANE_S + (2 * wave) * T::ROWP + 2 * n16;
+    const int a_base = T::IN_FLOATS + (k4 * 4 * T::BN + n16) * 4;
+    int slot = 0, cseq = -1;
+    for (int cL = next_valid(blockIdx.x); cL < Ltotal; cL = next_valid(cL + G)) {
+        ++cseq;
+        const Item it = decode_item(a, cL);
+        const int ch_begin = nchunks_all * it.split / a.splits;
+        const int ch_end = nchunks_all * (it.split + 1) / a.splits;
+        f32x4 acc[2][16];     // [16-channel half][frequency position 4*i + j]
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc[mb][p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+        for (int ch = ch_begin; ch < ch_end; ++ch) {
+            // The oldest chunk in flight has landed once no more than the DMA instructions of the DIST-1 younger chunks
+            // (>= MIN_LOADS each; an item's stores in between only make the wait earlier) are outstanding.  The barrier
+            // makes every wave's part visible and retires all reads of the slot that is refilled next.
+            static_assert((T::DIST - 1) * T::MIN_LOADS == 8, "update the counted wait");
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_next(slot == 0 ? T::NBUF - 1 : slot - 1);
+
+            const float *in_s = lds + slot * T::BUF + b_base;
+            const float *w_s = lds + slot * T::BUF + a_base;
+            float d[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[r][j] = in_s[r * T::ROWP + j];      // (scalar-typed: merged to 8-byte reads)
+            float4 ua[2][4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float *pu = w_s + (i * T::BN + mb * 16) * 4;
+                    ua[mb][i] = make_float4(pu[0], pu[1], pu[2], pu[3]);
+                }
+            float t[4][4], v[4][4];   // V = B^T d B
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i][0] = t[i][0] - t[i][2]; v[i][1] = t[i][1] + t[i][2];
+                v[i][2] = t[i][2] - t[i][1]; v[i][3] = t[i][1] - t[i][3];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    acc[mb][4 * i + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[mb][i].x, v[i][0], acc[mb][4 * i + 0], 0, 0, 0);
+                    acc[mb][4 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[mb][i].y, v[i][1], acc[mb][4 * i + 1], 0, 0, 0);
+                    acc[mb][4 * i + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[mb][i].z, v[i][2], acc[mb][4 * i + 2], 0, 0, 0);
+                    acc[mb][4 * i + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[mb][i].w, v[i][3], acc[mb][4 * i + 3], 0, 0, 0);
+                }
+            slot = slot + 1 == T::NBUF ? 0 : slot + 1;
+        }
+
+        // ---- item epilogue: Y = A^T M A per lane: channel co = nb*32 + mb*16 + 4*k4 + j, tile (row `wave`, column n16) ----
+        const int gxw = it.x0 + 2 * n16, gy0 = it.y0 + 2 * wave;
+        const bool split_out = a.splits > 1;   // split-K: raw partial sums; bias / activation / residual in the reduce kernel
+        const float *__restrict__ resp = (RES && !split_out && a.res) ? a.res + (size_t)it.n * a.res_bs : nullptr;
+        float *__restrict__ yp = split_out ? a.ws + ((size_t)it.split * N + it.n) * a.Cout * HW : a.y + (size_t)it.n * a.y_bs;
+        const int act = ACT >= 0 ? ACT : (split_out ? 0 : a.act);
+        const size_t pix = (size_t)gy0 * a.W + gxw;
+        // Fast path (wave-uniform): the tile lies inside the image and rows are 16-byte aligned.  Lane pairs (even /
+        // odd tile column) swap halves so that each lane stores ONE float4 per channel (the even lane the upper
+        // output row of both tiles, the odd lane the lower row): 8 stores per lane instead of 16.
+        const bool vec4 = it.x0 + T::TW <= a.W && it.y0 + T::TH <= a.H && (a.W % 4 == 0) && ((reinterpret_cast<size_t>(yp) & 15) == 0) &&
+                          (!resp || (reinterpret_cast<size_t>(resp) & 15) == 0);
+        const bool odd = n16 & 1;
+        const size_t pix4 = (size_t)(gy0 + (odd ? 1 : 0)) * a.W + (gxw & ~3);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float *bl = lds + T::BIAS_OFF + (cseq & (T::NBUF - 1)) * 64 + mb * 16 + 4 * k4;
+            const float bv[4] = {split_out ? 0.0f : bl[0], split_out ? 0.0f : bl[1], split_out ? 0.0f : bl[2], split_out ? 0.0f : bl[3]};
+            float4 rv4[4];
+            float2 rv2[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = min(it.nb * T::BN + mb * 16 + 4 * k4 + j, a.Cout - 1);
+                rv4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                rv2[j][0] = rv2[j][1] = make_float2(0.0f, 0.0f);
+                if (RES && resp) {
+                    if (vec4) {
+                        rv4[j] = *reinterpret_cast<const float4 *>(resp + (size_t)co * HW + pix4);
+                    } else if (gy0 < a.H && gxw < a.W) {
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy)
+                            if (gy0 + dy < a.H) {
+                                const float *rp = resp + (size_t)co * HW + pix + dy * a.W;
+                                rv2[j][dy].x = rp[0];
+                                if (gxw + 1 < a.W) rv2[j][dy].y = rp[1];
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = it.nb * T::BN + mb * 16 + 4 * k4 + j;
+                float s0[4], s1[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0[c] = acc[mb][c][j] + acc[mb][4 + c][j] + acc[mb][8 + c][j];
+                    s1[c] = acc[mb][4 + c][j] - acc[mb][8 + c][j] - acc[mb][12 + c][j];
+                }
+                float2 o[2];
+                o[0] = make_float2(s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]);
+                o[1] = make_float2(s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
+                if (vec4) {
+                    // quad_perm [1,0,3,2]: exchange with the neighbouring tile column
+                    const float2 give = odd ? o[0] : o[1];
+                    float2 got;
+                    got.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0xB1, 0xf, 0xf, false));
+                    got.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0xB1, 0xf, 0xf, false));
+                    float4 q = odd ? make_float4(got.x, got.y, o[1].x, o[1].y) : make_float4(o[0].x, o[0].y, got.x, got.y);
+                    q.x = apply_act(q.x + bv[j], act) + rv4[j].x;
+                    q.y = apply_act(q.y + bv[j], act) + rv4[j].y;
+                    q.z = apply_act(q.z + bv[j], act) + rv4[j].z;
+                    q.w = apply_act(q.w + bv[j], act) + rv4[j].w;
+                    if (co < a.Cout) *reinterpret_cast<float4 *>(yp + (size_t)co * HW + pix4) = q;
+                } else if (co < a.Cout && gy0 < a.H && gxw < a.W) {
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+                        if (gy0 + dy < a.H) {
+                            float *op = yp + (size_t)co * HW + pix + dy * a.W;
+                            op[0] = apply_act(o[dy].x + bv[j], act) + rv2[j][dy].x;
+                            if (gxw + 1 < a.W) op[1] = apply_act(o[dy].y + bv[j], act) + rv2[j][dy].y;
+                        }
+                }
+            }
+        }
+    }
+    // the (empty) look-ahead DMAs must have retired before the workgroup's LDS can be handed to another workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// 3x3 OIHW -> Winograd F(2x2,3x3) weights U = G g G^T as [Cin_pad][4 (row i)][Cout_pad][4 (column j)], BatchNorm
+// scale folded.  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; evaluated in double, rounded once.
+__global__ void conv2d_pack_winograd_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                            float *__restrict__ out, int Cout, int Cin, int Cin_pad, int Cout_pad) {
+    const size_t total = (size_t)Cin_pad * 16 * Cout_pad;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = e & 3, co = (e >> 2) % Cout_pad, i = (e / ((size_t)4 * Cout_pad)) & 3, ci = e / ((size_t)16 * Cout_pad);
+        double u = 0.0;
+        if (co < Cout && ci < Cin) {
+            const float *g = w + ((size_t)co * Cin + ci) * 9;
+            const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) u += G[i][r] * (double)g[r * 3 + c] * G[j][c];
+            if (scale) u *= (double)scale[co];
+        }
+        out[e] = (float)u;
+    }
+}
+
+}  // namespace
+
+void vfi::conv::launch_pack_winograd(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin, int Cin_pad,
+                                     int Cout_pad, hipStream_t s) {
+    const long long total = (long long)Cin_pad * 16 * Cout_pad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv2d_pack_winograd_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, scale, packed, Cout, Cin, Cin_pad, Cout_pad);
+}
+
+int vfi::conv::launch_winograd(const ConvArgs &a, int N, hipStream_t s) {
+    using T = WinoTile;
+    static int resident = 0;        // persistent grid: 2 workgroups per CU (idempotent; racing threads set the same value)
+    if (!resident) {
+        hipError_t e = hipSuccess;
+        for (const void *k : {reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 0>),
+                              reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 1>),
+                              reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 2>),
+                              reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 3>),
+                              reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 4>),
+                              reinterpret_cast<const void *>(conv3x3_winograd_kernel<true, -1>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+        int dev = 0, cus = 0;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || cus <= 0) return vfi::fail(VFI_ERR_LAUNCH, "vfi_conv2d: Winograd kernel setup: %s", hipGetErrorString(e));
+        resident = 2 * cus;
+    }
+    ConvArgs b = a;
+    const int cb = a.Cout_pad / T::BN;
+    b.wino_tiles = a.tiles_x * vfi::ceil_div(a.H, T::TH);
+    b.wino_batch = N;
+    b.wino_items = round_up(b.wino_tiles * N, 8) * cb;
+    // Split-K: few, long items (deep U-Net levels) leave most of the resident workgroups idle; splitting the channel
+    // loop S ways makes S times as many items of 1/S the length (partial sums reduced deterministically afterwards).
+    b.splits = 1;
+    const int nchunks = vfi::ceil_div(a.Cin, T::CK);
+    const long long out_floats = (long long)N * a.Cout * a.H * a.W;
+    if (a.ws && nchunks >= 16 && b.wino_items < 4 * resident) {
+        auto cost = [&](int S) { return (double)(((long long)b.wino_items * S + resident - 1) / resident) / S; };
+        int best = 1;
+        for (int S = 2; S <= 16; S *= 2)
+            if (nchunks / S >= 8 && out_floats * S <= a.ws_floats && cost(S) < cost(best) - 1e-9) best = S;
+        if (cost(best) <= 0.85 * cost(1)) b.splits = best;
+    }
+    const long long items = (long long)b.wino_items * b.splits;
+    dim3 grid((unsigned)(items < resident ? items : resident));
+    const int act = b.splits > 1 ? 0 : b.act;      // split-K: the reduce kernel applies bias / activation / residual
+    if (b.res && b.splits == 1) hipLaunchKernelGGL((conv3x3_winograd_kernel<true, -1>), grid, dim3(256), T::LDS_BYTES, s, b);
+    else if (act == 0) hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 0>), grid, dim3(256), T::LDS_BYTES, s, b);
+    else if (act == 1) hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 1>), grid, dim3(256), T::LDS_BYTES, s, b);
+    else if (act == 2) hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 2>), grid, dim3(256), T::LDS_BYTES, s, b);
+    else if (act == 3) hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 3>), grid, dim3(256), T::LDS_BYTES, s, b);
+    else hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 4>), grid, dim3(256), T::LDS_BYTES, s, b);
+    if (b.splits > 1) launch_splitk_reduce(b, N, s);
+    return vfi::check_launch("vfi_conv2d");
+}

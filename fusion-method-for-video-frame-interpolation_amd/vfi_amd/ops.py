@@ -4,6 +4,8 @@ Tensors are torch HIP tensors used purely as device-memory handles; every wrappe
 library call on torch's current stream.  Inputs / outputs may be CHANNEL SLICES of wider NCHW
 tensors (`t[:, a:b]`): only the batch stride is free, the (C, H, W) block must be dense.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -65,6 +67,7 @@ class PackedConv:
         self._keep = (weight, scale)  # alive until the pack kernel has run (same stream ordering)
 
 
+WINOGRAD = os.environ.get("VFI_CONV_WINOGRAD", "1") != "0"     # mirrors the library's switch (profiling labels only)
 _WORKSPACES = {}
 WORKSPACE_FLOATS = 48 * 1024 * 1024     # 192 MiB per (device, stream): split-K partial sums of the deep U-Net levels
 
@@ -101,9 +104,13 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2
     ws = _workspace(x.device)
     work = None
     if _lib.PROFILE is not None:
-        label = (f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}"
-                 + (",ups>" if upsample2x else ">"))
-        work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w, label)
+        if pc.ks == 3 and not upsample2x and WINOGRAD:
+            # F(2x2,3x3): 16 multiply-adds per 2x2 outputs and channel pair -- the algorithm's own flop count
+            work = ("flop", 2.0 * n * cin * pc.cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")
+        else:
+            label = (f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}"
+                     + (",ups>" if upsample2x else ">"))
+            work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w, label)
     _lib.call("vfi_conv2d_upsample2x" if upsample2x else "vfi_conv2d", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), rp, rs, yp, ys,
               n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], ws.data_ptr(), ws.numel(), _lib.stream_ptr(), work=work)
     return out

@@ -91,7 +91,7 @@ def test_frame_is_capturable_into_a_hip_graph(device):
     a0, _, a2 = (torch.from_numpy(x).to(device) for x in synth.translating_pair(5, 64, 96))
     b0, _, b2 = (torch.from_numpy(x).to(device) for x in synth.translating_pair(6, 64, 96))
     want_a = run(a0, a2)["final"].clone()          # also warms up plans / packed weights
-    want_b = run(b0, b2)["final"].clone()
+    torch.cuda.synchronize()
     s = torch.cuda.Stream(device=device)
     f0, f2 = torch.empty_like(a0), torch.empty_like(a2)
     g = torch.cuda.CUDAGraph()
@@ -106,4 +106,11 @@ def test_frame_is_capturable_into_a_hip_graph(device):
         f0.copy_(b0); f2.copy_(b2)
         g.replay()
         s.synchronize()
-        assert torch.equal(out, want_b)
+        got_b = out.clone()
+    torch.cuda.synchronize()
+    # the eager reference for the second input pair is taken AFTER the replay: nothing of it can have been around
+    # while the graph was captured or replayed
+    want_b = run(b0, b2)["final"]
+    torch.cuda.synchronize()
+    assert torch.equal(got_b, want_b)
+    assert not torch.equal(got_b, want_a)
