@@ -45,7 +45,7 @@ struct WinoTile {
     static constexpr int IN_FLOATS = IN_X4 * 1024;        // 2048 >= IN_X1 * 256
     static constexpr int W_FLOATS = CK * 16 * BN, W_INSTR = W_FLOATS / 4 / 256;   // 2048 floats, 2 per wave
     static constexpr int BUF = IN_FLOATS + W_FLOATS;      // 16 KiB
-    static constexpr int NBUF = 4, DIST = NBUF - 1;
+    static constexpr int NBUF = 4;
     static constexpr int MIN_LOADS = IN_X4 + W_INSTR;     // fewest DMA instructions a chunk issues per wave
     static constexpr int BIAS_OFF = NBUF * BUF;          // NBUF x 64 floats: the bias of the items in flight
     static constexpr size_t LDS_BYTES = ((size_t)NBUF * BUF + NBUF * 64) * sizeof(float);
@@ -109,18 +109,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
     // ------------------------------------------------------------------------------------------------------------
     // DMA side ("issue cursor"): item iL, chunk ich of [.., ich_end); per-lane source offsets of the item's tile
     // ------------------------------------------------------------------------------------------------------------
-    int iL = next_valid(blockIdx.x), ich = 0, ich_end = 0, iseq = -1, inb = 0;
+    // Per chunk the cursor only moves two addresses and two counters (scalar adds): the descriptors are rebuilt from
+    // them, nothing is multiplied or divided in the chunk loop.
+    int iL = next_valid(blockIdx.x), ileft = 0, iseq = -1, inb = 0;      // ileft: chunks of the item still to request
+    unsigned in_bytes_left = 0;                                              // bytes from the chunk's first channel to the input's end
+    const char *in_ptr = nullptr, *w_ptr = nullptr;
     bool iborder = false, ifirst = false;
     unsigned voff[T::IN_X1], woff[T::W_INSTR];
-    const char *ixn = nullptr;
+    const unsigned in_chunk_bytes = (unsigned)T::CK * (unsigned)HW * 4u, w_chunk_bytes = (unsigned)T::CK * 4u * (unsigned)a.Cout_pad * 16u;
     auto setup_issue = [&]() {
         const Item it = decode_item(a, iL);
         ++iseq;
         ifirst = true;
         inb = it.nb;
-        ich = nchunks_all * it.split / a.splits;
-        ich_end = nchunks_all * (it.split + 1) / a.splits;
-        ixn = reinterpret_cast<const char *>(a.x + (size_t)it.n * a.x_bs);
+        const int ch0 = nchunks_all * it.split / a.splits;
+        ileft = nchunks_all * (it.split + 1) / a.splits - ch0;
+        in_ptr = reinterpret_cast<const char *>(a.x + (size_t)it.n * a.x_bs) + (size_t)ch0 * in_chunk_bytes;
+        in_bytes_left = (unsigned)(a.Cin - ch0 * T::CK) * (unsigned)HW * 4u;       // (host: Cin*H*W*4 < 2^32)
+        w_ptr = reinterpret_cast<const char *>(a.wp) + (size_t)ch0 * w_chunk_bytes;
         iborder = it.x0 == 0 || it.x0 + T::TW >= a.W;      // a fetched 16-byte piece would wrap around an image row
         if (iborder) {
 #pragma unroll
@@ -155,20 +161,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
             woff[t] = (unsigned)(((f / T::BN) * a.Cout_pad + it.nb * T::BN + f % T::BN) * 16);
         }
     };
-    const char *wn = reinterpret_cast<const char *>(a.wp);
-    const size_t in_chunk_bytes = (size_t)T::CK * HW * 4, w_chunk_bytes = (size_t)T::CK * 4 * a.Cout_pad * 16;
 
     // Requests the next chunk of this workgroup's item sequence into ring slot `slot` and advances the cursor.  Past
     // the end it still issues MIN_LOADS (empty) DMA instructions so that the counted wait below stays valid.
     auto issue_next = [&](int slot) {
         float *b = lds + uni(slot) * T::BUF;
         const bool live = uni(iL) < Ltotal;
-        const int uch = uni(ich);
         const bool border = uni(iborder ? 1 : 0) != 0, first = uni(ifirst ? 1 : 0) != 0;
-        const long long in_left = live ? ((long long)a.Cin - (long long)uch * T::CK) * HW * 4 : 0;   // channel tail -> 0
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc(uni(live ? ixn + uch * in_chunk_bytes : wn),
-                                                    (unsigned)uni((int)(unsigned)(in_left > 0xffffffffll ? 0xffffffffll : in_left)));
-        const __amdgpu_buffer_rsrc_t rw = make_rsrc(uni(live ? wn + uch * w_chunk_bytes : wn), live ? (unsigned)w_chunk_bytes : 0u);
+        // (the channel tail and everything past the end read as 0: zero-sized / shortened buffers)
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(uni(in_ptr), live ? (unsigned)uni((int)in_bytes_left) : 0u);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(uni(w_ptr), live ? w_chunk_bytes : 0u);
         if (live && border) {
 #pragma unroll
             for (int i = 0; i < T::IN_X1; ++i)
@@ -188,158 +190,216 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
         // the whole DMA ring (vmcnt(0)) before its first use.  (More DMA instructions only make the counted wait
         // earlier; a null / short bias reads as 0.)
         if (live && first && uni(wave) == 0) {
-            const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? a.bias : a.wp, a.bias ? (unsigned)a.Cout * 4u : 0u);
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? a.bias : a.x, a.bias ? (unsigned)a.Cout * 4u : 0u);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(lds + T::BIAS_OFF + (uni(iseq) & (T::NBUF - 1)) * 64),
                                                      4, lane < T::BN ? (unsigned)(uni(inb) * T::BN + lane) * 4u : 0xffffffffu, 0, 0, 0);
         }
         ifirst = false;
-        if (live && ++ich == ich_end) {
-            iL = next_valid(iL + G);
-            if (iL < Ltotal) setup_issue();
+        if (live) {
+            in_ptr += in_chunk_bytes;
+            w_ptr += w_chunk_bytes;
+            in_bytes_left = in_bytes_left > in_chunk_bytes ? in_bytes_left - in_chunk_bytes : 0u;
+            if (--ileft == 0) {
+                iL = next_valid(iL + G);
+                if (iL < Ltotal) setup_issue();
+            }
         }
     };
     if (iL < Ltotal) setup_issue();
 #pragma unroll
-    for (int p = 0; p < T::DIST; ++p) issue_next(p);
+    for (int p = 0; p < T::NBUF; ++p) issue_next(p);
 
     // ------------------------------------------------------------------------------------------------------------
-    // MFMA side
+    // MFMA side: a software pipeline over the workgroup's flattened (item, chunk) sequence, in half chunks (rows 0-1
+    // and rows 2-3 of the 4x4 frequency grid, 16 MFMAs each).  While one half's MFMAs issue, the operands of the next
+    // half are fetched from LDS:
+    //     [fetch U rows 2-3 of c]   MFMA rows 0-1 of c
+    //     wait + barrier            (chunk c+1 visible to everyone, everyone's reads of chunk c retired)
+    //     DMA chunk c+NBUF -> slot of c ; [fetch patch + U rows 0-1 of c+1]   MFMA rows 2-3 of c ; V(c+1) = B^T d B
+    // so neither the LDS latency nor the DMA issue sits in front of an MFMA, and one barrier per chunk remains.
     // ------------------------------------------------------------------------------------------------------------
     const int b_base = k4 * T::PLANE_S + (2 * wave) * T::ROWP + 2 * n16;
     const int a_base = T::IN_FLOATS + (k4 * 4 * T::BN + n16) * 4;
-    int slot = 0, cseq = -1;
-    for (int cL = next_valid(blockIdx.x); cL < Ltotal; cL = next_valid(cL + G)) {
-        ++cseq;
-        const Item it = decode_item(a, cL);
-        const int ch_begin = nchunks_all * it.split / a.splits;
-        const int ch_end = nchunks_all * (it.split + 1) / a.splits;
-        f32x4 acc[2][16];     // [16-channel half][frequency position 4*i + j]
+    auto fetch_u = [&](float4 (&u)[2][2], int slot, int i_begin) {       // U rows i_begin, i_begin+1 for both channel halves
+        const float *w_s = lds + slot * T::BUF + a_base;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float *pu = w_s + ((i_begin + i) * T::BN + mb * 16) * 4;      // (scalar-typed: merged to ds_read_b128)
+                u[mb][i] = make_float4(pu[0], pu[1], pu[2], pu[3]);
+            }
+    };
+    auto fetch_d = [&](float (&d)[4][4], int slot) {                    // this lane's raw 4x4 patch
+        const float *in_s = lds + slot * T::BUF + b_base;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[r][j] = in_s[r * T::ROWP + j];      // (merged to 8-byte reads)
+    };
+    auto transform = [&](const float (&d)[4][4], float (&v)[4][4]) {    // V = B^T d B
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j];
+            t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i][0] = t[i][0] - t[i][2]; v[i][1] = t[i][1] + t[i][2];
+            v[i][2] = t[i][2] - t[i][1]; v[i][3] = t[i][1] - t[i][3];
+        }
+    };
+    f32x4 acc[2][16];     // [16-channel half][frequency position 4*i + j]
+    auto zero_acc = [&]() {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int p = 0; p < 16; ++p) acc[mb][p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-        for (int ch = ch_begin; ch < ch_end; ++ch) {
-            // The oldest chunk in flight has landed once no more than the DMA instructions of the DIST-1 younger chunks
-            // (>= MIN_LOADS each; an item's stores in between only make the wait earlier) are outstanding.  The barrier
-            // makes every wave's part visible and retires all reads of the slot that is refilled next.
-            static_assert((T::DIST - 1) * T::MIN_LOADS == 8, "update the counted wait");
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            issue_next(slot == 0 ? T::NBUF - 1 : slot - 1);
-
-            const float *in_s = lds + slot * T::BUF + b_base;
-            const float *w_s = lds + slot * T::BUF + a_base;
-            float d[4][4];
+    };
+    auto mfma_rows = [&](const float4 (&u)[2][2], const float (&v)[4][4], int i_begin) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[r][j] = in_s[r * T::ROWP + j];      // (scalar-typed: merged to 8-byte reads)
-            float4 ua[2][4];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float *pu = w_s + (i * T::BN + mb * 16) * 4;
-                    ua[mb][i] = make_float4(pu[0], pu[1], pu[2], pu[3]);
-                }
-            float t[4][4], v[4][4];   // V = B^T d B
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j];
-                t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+            for (int mb = 0; mb < 2; ++mb) {
+                const int r = i_begin + i;
+                acc[mb][4 * r + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[mb][i].x, v[r][0], acc[mb][4 * r + 0], 0, 0, 0);
+                acc[mb][4 * r + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[mb][i].y, v[r][1], acc[mb][4 * r + 1], 0, 0, 0);
+                acc[mb][4 * r + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[mb][i].z, v[r][2], acc[mb][4 * r + 2], 0, 0, 0);
+                acc[mb][4 * r + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[mb][i].w, v[r][3], acc[mb][4 * r + 3], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i][0] = t[i][0] - t[i][2]; v[i][1] = t[i][1] + t[i][2];
-                v[i][2] = t[i][2] - t[i][1]; v[i][3] = t[i][1] - t[i][3];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    acc[mb][4 * i + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[mb][i].x, v[i][0], acc[mb][4 * i + 0], 0, 0, 0);
-                    acc[mb][4 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[mb][i].y, v[i][1], acc[mb][4 * i + 1], 0, 0, 0);
-                    acc[mb][4 * i + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[mb][i].z, v[i][2], acc[mb][4 * i + 2], 0, 0, 0);
-                    acc[mb][4 * i + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[mb][i].w, v[i][3], acc[mb][4 * i + 3], 0, 0, 0);
-                }
-            slot = slot + 1 == T::NBUF ? 0 : slot + 1;
-        }
+    };
 
-        // ---- item epilogue: Y = A^T M A per lane: channel co = nb*32 + mb*16 + 4*k4 + j, tile (row `wave`, column n16) ----
-        const int gxw = it.x0 + 2 * n16, gy0 = it.y0 + 2 * wave;
-        const bool split_out = a.splits > 1;   // split-K: raw partial sums; bias / activation / residual in the reduce kernel
-        const float *__restrict__ resp = (RES && !split_out && a.res) ? a.res + (size_t)it.n * a.res_bs : nullptr;
-        float *__restrict__ yp = split_out ? a.ws + ((size_t)it.split * N + it.n) * a.Cout * HW : a.y + (size_t)it.n * a.y_bs;
-        const int act = ACT >= 0 ? ACT : (split_out ? 0 : a.act);
-        const size_t pix = (size_t)gy0 * a.W + gxw;
-        // Fast path (wave-uniform): the tile lies inside the image and rows are 16-byte aligned.  Lane pairs (even /
-        // odd tile column) swap halves so that each lane stores ONE float4 per channel (the even lane the upper
-        // output row of both tiles, the odd lane the lower row): 8 stores per lane instead of 16.
-        const bool vec4 = it.x0 + T::TW <= a.W && it.y0 + T::TH <= a.H && (a.W % 4 == 0) && ((reinterpret_cast<size_t>(yp) & 15) == 0) &&
-                          (!resp || (reinterpret_cast<size_t>(resp) & 15) == 0);
-        const bool odd = n16 & 1;
-        const size_t pix4 = (size_t)(gy0 + (odd ? 1 : 0)) * a.W + (gxw & ~3);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const float *bl = lds + T::BIAS_OFF + (cseq & (T::NBUF - 1)) * 64 + mb * 16 + 4 * k4;
-            const float bv[4] = {split_out ? 0.0f : bl[0], split_out ? 0.0f : bl[1], split_out ? 0.0f : bl[2], split_out ? 0.0f : bl[3]};
-            float4 rv4[4];
-            float2 rv2[4][2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = min(it.nb * T::BN + mb * 16 + 4 * k4 + j, a.Cout - 1);
-                rv4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                rv2[j][0] = rv2[j][1] = make_float2(0.0f, 0.0f);
-                if (RES && resp) {
+    int cL = next_valid(blockIdx.x);
+    if (cL >= Ltotal) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    Item it = decode_item(a, cL);
+    int ch = nchunks_all * it.split / a.splits, ch_end = nchunks_all * (it.split + 1) / a.splits;
+    int slot = 0, cseq = 0;
+    // The oldest chunk in flight has landed once no more than the DMA instructions of the younger chunks in flight are
+    // outstanding (>= MIN_LOADS each; an item's stores in between only make the wait earlier).  The barrier makes every
+    // wave's part visible.
+    static_assert((T::NBUF - 1) * T::MIN_LOADS == 12 && (T::NBUF - 2) * T::MIN_LOADS == 8, "update the counted waits");
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float4 u01[2][2], u23[2][2];
+    float v[4][4];
+    {
+        float d[4][4];
+        fetch_d(d, 0);
+        fetch_u(u01, 0, 0);
+        transform(d, v);
+    }
+    zero_acc();
+    while (true) {
+        fetch_u(u23, slot, 2);
+        __builtin_amdgcn_sched_barrier(0);      // (keep the LDS reads in front of the MFMAs they overlap with)
+        mfma_rows(u01, v, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's reads of the current slot are done; after the barrier everyone's are, and chunk c+1 is visible
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const int cur_slot = slot;
+        slot = slot + 1 == T::NBUF ? 0 : slot + 1;
+        float d[4][4];
+        fetch_d(d, slot);              // (after the workgroup's last chunk: an empty look-ahead slot, unused)
+        fetch_u(u01, slot, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(u23, v, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_next(cur_slot);          // its issue cost overlaps the matrix-core work queued above
+        transform(d, v);
+        const bool last_of_item = ch + 1 == ch_end;
+        const int nL = last_of_item ? next_valid(cL + G) : cL;
+        const bool more = nL < Ltotal;
+        ++ch;
+        if (last_of_item) {
+            // ---- item epilogue: Y = A^T M A per lane: channel co = nb*32 + mb*16 + 4*k4 + j, tile (row `wave`, column n16) ----
+            const int gxw = it.x0 + 2 * n16, gy0 = it.y0 + 2 * wave;
+            const bool split_out = a.splits > 1;   // split-K: raw partial sums; bias / activation / residual in the reduce kernel
+            const float *__restrict__ resp = (RES && !split_out && a.res) ? a.res + (size_t)it.n * a.res_bs : nullptr;
+            float *__restrict__ yp = split_out ? a.ws + ((size_t)it.split * N + it.n) * a.Cout * HW : a.y + (size_t)it.n * a.y_bs;
+            const int act = ACT >= 0 ? ACT : (split_out ? 0 : a.act);
+            const size_t pix = (size_t)gy0 * a.W + gxw;
+            // Fast path (wave-uniform): the tile lies inside the image and rows are 16-byte aligned.  Lane pairs (even /
+            // odd tile column) swap halves so that each lane stores ONE float4 per channel (the even lane the upper
+            // output row of both tiles, the odd lane the lower row): 8 stores per lane instead of 16.
+            const bool vec4 = it.x0 + T::TW <= a.W && it.y0 + T::TH <= a.H && (a.W % 4 == 0) && ((reinterpret_cast<size_t>(yp) & 15) == 0) &&
+                              (!resp || (reinterpret_cast<size_t>(resp) & 15) == 0);
+            const bool odd = n16 & 1;
+            const size_t pix4 = (size_t)(gy0 + (odd ? 1 : 0)) * a.W + (gxw & ~3);
+    #pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const float *bl = lds + T::BIAS_OFF + (cseq & (T::NBUF - 1)) * 64 + mb * 16 + 4 * k4;
+                const float bv[4] = {split_out ? 0.0f : bl[0], split_out ? 0.0f : bl[1], split_out ? 0.0f : bl[2], split_out ? 0.0f : bl[3]};
+                float4 rv4[4];
+                float2 rv2[4][2];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = min(it.nb * T::BN + mb * 16 + 4 * k4 + j, a.Cout - 1);
+                    rv4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    rv2[j][0] = rv2[j][1] = make_float2(0.0f, 0.0f);
+                    if (RES && resp) {
+                        if (vec4) {
+                            rv4[j] = *reinterpret_cast<const float4 *>(resp + (size_t)co * HW + pix4);
+                        } else if (gy0 < a.H && gxw < a.W) {
+    #pragma unroll
+                            for (int dy = 0; dy < 2; ++dy)
+                                if (gy0 + dy < a.H) {
+                                    const float *rp = resp + (size_t)co * HW + pix + dy * a.W;
+                                    rv2[j][dy].x = rp[0];
+                                    if (gxw + 1 < a.W) rv2[j][dy].y = rp[1];
+                                }
+                        }
+                    }
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = it.nb * T::BN + mb * 16 + 4 * k4 + j;
+                    float s0[4], s1[4];
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s0[c] = acc[mb][c][j] + acc[mb][4 + c][j] + acc[mb][8 + c][j];
+                        s1[c] = acc[mb][4 + c][j] - acc[mb][8 + c][j] - acc[mb][12 + c][j];
+                    }
+                    float2 o[2];
+                    o[0] = make_float2(s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]);
+                    o[1] = make_float2(s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
                     if (vec4) {
-                        rv4[j] = *reinterpret_cast<const float4 *>(resp + (size_t)co * HW + pix4);
-                    } else if (gy0 < a.H && gxw < a.W) {
-#pragma unroll
+                        // quad_perm [1,0,3,2]: exchange with the neighbouring tile column
+                        const float2 give = odd ? o[0] : o[1];
+                        float2 got;
+                        got.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0xB1, 0xf, 0xf, false));
+                        got.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0xB1, 0xf, 0xf, false));
+                        float4 q = odd ? make_float4(got.x, got.y, o[1].x, o[1].y) : make_float4(o[0].x, o[0].y, got.x, got.y);
+                        q.x = apply_act(q.x + bv[j], act) + rv4[j].x;
+                        q.y = apply_act(q.y + bv[j], act) + rv4[j].y;
+                        q.z = apply_act(q.z + bv[j], act) + rv4[j].z;
+                        q.w = apply_act(q.w + bv[j], act) + rv4[j].w;
+                        if (co < a.Cout) *reinterpret_cast<float4 *>(yp + (size_t)co * HW + pix4) = q;
+                    } else if (co < a.Cout && gy0 < a.H && gxw < a.W) {
+    #pragma unroll
                         for (int dy = 0; dy < 2; ++dy)
                             if (gy0 + dy < a.H) {
-                                const float *rp = resp + (size_t)co * HW + pix + dy * a.W;
-                                rv2[j][dy].x = rp[0];
-                                if (gxw + 1 < a.W) rv2[j][dy].y = rp[1];
+                                float *op = yp + (size_t)co * HW + pix + dy * a.W;
+                                op[0] = apply_act(o[dy].x + bv[j], act) + rv2[j][dy].x;
+                                if (gxw + 1 < a.W) op[1] = apply_act(o[dy].y + bv[j], act) + rv2[j][dy].y;
                             }
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = it.nb * T::BN + mb * 16 + 4 * k4 + j;
-                float s0[4], s1[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s0[c] = acc[mb][c][j] + acc[mb][4 + c][j] + acc[mb][8 + c][j];
-                    s1[c] = acc[mb][4 + c][j] - acc[mb][8 + c][j] - acc[mb][12 + c][j];
-                }
-                float2 o[2];
-                o[0] = make_float2(s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]);
-                o[1] = make_float2(s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
-                if (vec4) {
-                    // quad_perm [1,0,3,2]: exchange with the neighbouring tile column
-                    const float2 give = odd ? o[0] : o[1];
-                    float2 got;
-                    got.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0xB1, 0xf, 0xf, false));
-                    got.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0xB1, 0xf, 0xf, false));
-                    float4 q = odd ? make_float4(got.x, got.y, o[1].x, o[1].y) : make_float4(o[0].x, o[0].y, got.x, got.y);
-                    q.x = apply_act(q.x + bv[j], act) + rv4[j].x;
-                    q.y = apply_act(q.y + bv[j], act) + rv4[j].y;
-                    q.z = apply_act(q.z + bv[j], act) + rv4[j].z;
-                    q.w = apply_act(q.w + bv[j], act) + rv4[j].w;
-                    if (co < a.Cout) *reinterpret_cast<float4 *>(yp + (size_t)co * HW + pix4) = q;
-                } else if (co < a.Cout && gy0 < a.H && gxw < a.W) {
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-                        if (gy0 + dy < a.H) {
-                            float *op = yp + (size_t)co * HW + pix + dy * a.W;
-                            op[0] = apply_act(o[dy].x + bv[j], act) + rv2[j][dy].x;
-                            if (gxw + 1 < a.W) op[1] = apply_act(o[dy].y + bv[j], act) + rv2[j][dy].y;
-                        }
-                }
-            }
+            if (!more) break;
+            cL = nL;
+            ++cseq;
+            it = decode_item(a, cL);
+            ch = nchunks_all * it.split / a.splits;
+            ch_end = nchunks_all * (it.split + 1) / a.splits;
+            zero_acc();
         }
     }
     // the (empty) look-ahead DMAs must have retired before the workgroup's LDS can be handed to another workgroup

@@ -68,6 +68,9 @@ class PackedConv:
 
 
 WINOGRAD = os.environ.get("VFI_CONV_WINOGRAD", "1") != "0"     # mirrors the library's switch (profiling labels only)
+# 3x3 convs whose input is a bilinear resize: materialise the resize and use the Winograd kernel (default), or keep the
+# direct kernels with the interpolating tile loader (VFI_CONV_FUSED_RESIZE=1; always when Winograd is off)
+FUSED_RESIZE = (not WINOGRAD) or os.environ.get("VFI_CONV_FUSED_RESIZE", "0") == "1"
 _WORKSPACES = {}
 WORKSPACE_FLOATS = 48 * 1024 * 1024     # 192 MiB per (device, stream): split-K partial sums of the deep U-Net levels
 
@@ -86,10 +89,15 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2
     input of an `Upsample(x2, bilinear, align_corners=True) -> conv` pair (the upsampled tensor is not
     materialised)."""
     n, cin, h, w = x.shape
-    if upsample2x:
-        h, w = 2 * h, 2 * w
     if cin != pc.cin:
         raise VfiLibraryError(f"conv2d: input has {cin} channels, weights expect {pc.cin}")
+    if upsample2x and pc.ks == 3 and not FUSED_RESIZE:
+        # the Winograd kernel reads its input by LDS-DMA and cannot interpolate on the fly: one streaming resize pass
+        # (HBM-bound, a few % of the conv) + the Winograd conv beats the direct kernel with the fused loader
+        x = resize_bilinear(x, (2 * h, 2 * w), align_corners=True)
+        h, w, upsample2x = 2 * h, 2 * w, False
+    if upsample2x:
+        h, w = 2 * h, 2 * w
     if out is None:
         out = new((n, pc.cout, h, w), x)
     elif tuple(out.shape) != (n, pc.cout, h, w):
@@ -123,6 +131,9 @@ def conv2d_resized_prefix(x, x2, pc, pad_mode="reflect", act=None, out=None):
     n2, c2, hs, ws_ = x2.shape
     if cin != pc.cin or n2 != n:
         raise VfiLibraryError("conv2d_resized_prefix: shape mismatch")
+    if pc.ks == 3 and not FUSED_RESIZE:      # see conv2d(upsample2x=True)
+        resize_bilinear(x2, (h, w), align_corners=False, out=x[:, :c2])
+        return conv2d(x, pc, pad_mode=pad_mode, act=act, out=out)
     if out is None:
         out = new((n, pc.cout, h, w), x)
     xp, xs = _slice_ptr(x, "x")
