@@ -72,64 +72,65 @@ __global__ void pool2_kernel_unaligned(const float *__restrict__ x, long long x_
 // ---- bilinear resize (torch upsample_bilinear2d semantics) -------------------------------------------
 // align_corners=True, x2: fusion_adacofnet.py:30,42,54,68; align_corners=False to an arbitrary size:
 // phase_net.py:138-139; align_corners=False, x2 after ReLU, + skip: fusion_net.py:65-67.
-__global__ void resize_bilinear_kernel(const float *__restrict__ x, long long x_bs, const float *__restrict__ res,
-                                       long long res_bs, float *__restrict__ y, long long y_bs, int N, int C,
-                                       int Hi, int Wi, int Ho, int Wo, int align_corners, int relu_in) {
+// Launch geometry of both forms: blockIdx.z = n*C + c (one plane), blockIdx.y * 4 + threadIdx.y = output row,
+// blockIdx.x * 64 + threadIdx.x = output column (or column quad): no integer division per element.
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__restrict__ x, long long x_bs,
+                                                              const float *__restrict__ res, long long res_bs,
+                                                              float *__restrict__ y, long long y_bs, int C, int Hi, int Wi,
+                                                              int Ho, int Wo, int align_corners, int relu_in) {
+    const int xo = blockIdx.x * 64 + threadIdx.x, yo = blockIdx.y * 4 + threadIdx.y;
+    if (xo >= Wo || yo >= Ho) return;
+    const int n = blockIdx.z / C, c = blockIdx.z - n * C;
     const float sy = align_corners ? (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f) : (float)Hi / (float)Ho;
     const float sx = align_corners ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f) : (float)Wi / (float)Wo;
-    const long long total = (long long)N * C * Ho * Wo;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int xo = i % Wo, yo = (i / Wo) % Ho, c = (i / ((long long)Wo * Ho)) % C, n = i / ((long long)Wo * Ho * C);
-        float fy = align_corners ? sy * yo : fmaxf(sy * (yo + 0.5f) - 0.5f, 0.0f);
-        float fx = align_corners ? sx * xo : fmaxf(sx * (xo + 0.5f) - 0.5f, 0.0f);
-        const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
-        const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
-        const float *p = x + (size_t)n * x_bs + (size_t)c * Hi * Wi;
-        float v00 = p[(size_t)y0 * Wi + x0], v01 = p[(size_t)y0 * Wi + x1];
-        float v10 = p[(size_t)y1 * Wi + x0], v11 = p[(size_t)y1 * Wi + x1];
-        if (relu_in) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
-        float v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
-        const size_t o = ((size_t)c * Ho + yo) * Wo + xo;
-        if (res) v += res[(size_t)n * res_bs + o];
-        y[(size_t)n * y_bs + o] = v;
-    }
+    const float fy = align_corners ? sy * yo : fmaxf(sy * (yo + 0.5f) - 0.5f, 0.0f);
+    const float fx = align_corners ? sx * xo : fmaxf(sx * (xo + 0.5f) - 0.5f, 0.0f);
+    const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
+    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float *p = x + (size_t)n * x_bs + (size_t)c * Hi * Wi;
+    float v00 = p[(size_t)y0 * Wi + x0], v01 = p[(size_t)y0 * Wi + x1];
+    float v10 = p[(size_t)y1 * Wi + x0], v11 = p[(size_t)y1 * Wi + x1];
+    if (relu_in) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+    float v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+    const size_t o = ((size_t)c * Ho + yo) * Wo + xo;
+    if (res) v += res[(size_t)n * res_bs + o];
+    y[(size_t)n * y_bs + o] = v;
 }
 
-// 4 consecutive outputs per thread (16-B store / residual load): used when Wout % 4 == 0 and pointers allow
-__global__ void resize_bilinear_vec4_kernel(const float *__restrict__ x, long long x_bs, const float *__restrict__ res,
-                                            long long res_bs, float *__restrict__ y, long long y_bs, int N, int C,
-                                            int Hi, int Wi, int Ho, int Wo, int align_corners, int relu_in) {
+// four consecutive output columns per thread, one 16-byte store
+__global__ __launch_bounds__(256) void resize_bilinear_vec4_kernel(const float *__restrict__ x, long long x_bs,
+                                                                   const float *__restrict__ res, long long res_bs,
+                                                                   float *__restrict__ y, long long y_bs, int C, int Hi, int Wi,
+                                                                   int Ho, int Wo, int align_corners, int relu_in) {
+    const int xq = blockIdx.x * 64 + threadIdx.x, yo = blockIdx.y * 4 + threadIdx.y;
+    if (xq * 4 >= Wo || yo >= Ho) return;
+    const int n = blockIdx.z / C, c = blockIdx.z - n * C;
     const float sy = align_corners ? (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f) : (float)Hi / (float)Ho;
     const float sx = align_corners ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f) : (float)Wi / (float)Wo;
-    const int Wq = Wo / 4;
-    const long long total = (long long)N * C * Ho * Wq;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int xq = i % Wq, yo = (i / Wq) % Ho, c = (i / ((long long)Wq * Ho)) % C, n = i / ((long long)Wq * Ho * C);
-        const float fy = align_corners ? sy * yo : fmaxf(sy * (yo + 0.5f) - 0.5f, 0.0f);
-        const int y0 = min((int)fy, Hi - 1), y1 = min(y0 + 1, Hi - 1);
-        const float ly = fy - (float)y0;
-        const float *p0 = x + (size_t)n * x_bs + ((size_t)c * Hi + y0) * Wi;
-        const float *p1 = x + (size_t)n * x_bs + ((size_t)c * Hi + y1) * Wi;
-        float out[4];
+    const float fy = align_corners ? sy * yo : fmaxf(sy * (yo + 0.5f) - 0.5f, 0.0f);
+    const int y0 = min((int)fy, Hi - 1), y1 = min(y0 + 1, Hi - 1);
+    const float ly = fy - (float)y0;
+    const float *p0 = x + (size_t)n * x_bs + ((size_t)c * Hi + y0) * Wi;
+    const float *p1 = x + (size_t)n * x_bs + ((size_t)c * Hi + y1) * Wi;
+    float out[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int xo = xq * 4 + k;
-            const float fx = align_corners ? sx * xo : fmaxf(sx * (xo + 0.5f) - 0.5f, 0.0f);
-            const int x0 = min((int)fx, Wi - 1), x1 = min(x0 + 1, Wi - 1);
-            const float lx = fx - (float)x0;
-            float v00 = p0[x0], v01 = p0[x1], v10 = p1[x0], v11 = p1[x1];
-            if (relu_in) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
-            out[k] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
-        }
-        const size_t o = ((size_t)c * Ho + yo) * Wo + (size_t)xq * 4;
-        float4 v = make_float4(out[0], out[1], out[2], out[3]);
-        if (res) {
-            const float4 r = *reinterpret_cast<const float4 *>(res + (size_t)n * res_bs + o);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-        }
-        *reinterpret_cast<float4 *>(y + (size_t)n * y_bs + o) = v;
+    for (int k = 0; k < 4; ++k) {
+        const int xo = xq * 4 + k;
+        const float fx = align_corners ? sx * xo : fmaxf(sx * (xo + 0.5f) - 0.5f, 0.0f);
+        const int x0 = min((int)fx, Wi - 1), x1 = min(x0 + 1, Wi - 1);
+        const float lx = fx - (float)x0;
+        float v00 = p0[x0], v01 = p0[x1], v10 = p1[x0], v11 = p1[x1];
+        if (relu_in) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+        out[k] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
     }
+    const size_t o = ((size_t)c * Ho + yo) * Wo + (size_t)xq * 4;
+    float4 v = make_float4(out[0], out[1], out[2], out[3]);
+    if (res) {
+        const float4 r = *reinterpret_cast<const float4 *>(res + (size_t)n * res_bs + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    *reinterpret_cast<float4 *>(y + (size_t)n * y_bs + o) = v;
 }
 
 // ---- single-output-channel `Upsample(x2, align_corners=True) -> Conv2d(C, 1, 3, padding=1)` tail ------------------
@@ -307,12 +308,14 @@ extern "C" int vfi_resize_bilinear(const float *x, long long x_bstride, const fl
                 "vfi_resize_bilinear: bad sizes");
     const bool vec = Wout % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0 && y_bstride % 4 == 0 &&
                      (!residual || ((reinterpret_cast<uintptr_t>(residual) & 15u) == 0 && res_bstride % 4 == 0));
+    VFI_REQUIRE((long long)N * C <= 65535, VFI_ERR_UNSUPPORTED, "vfi_resize_bilinear: N*C = %lld planes", (long long)N * C);
+    const dim3 block(64, 4), grid(ceil_div(vec ? Wout / 4 : Wout, 64), ceil_div(Hout, 4), N * C);
     if (vec)
-        LAUNCH_1D(resize_bilinear_vec4_kernel, (long long)N * C * Hout * (Wout / 4), stream, x, x_bstride, residual,
-                  res_bstride, y, y_bstride, N, C, Hin, Win, Hout, Wout, align_corners, relu_input);
+        hipLaunchKernelGGL(resize_bilinear_vec4_kernel, grid, block, 0, vfi::as_stream(stream), x, x_bstride, residual,
+                           res_bstride, y, y_bstride, C, Hin, Win, Hout, Wout, align_corners, relu_input);
     else
-        LAUNCH_1D(resize_bilinear_kernel, (long long)N * C * Hout * Wout, stream, x, x_bstride, residual, res_bstride, y,
-                  y_bstride, N, C, Hin, Win, Hout, Wout, align_corners, relu_input);
+        hipLaunchKernelGGL(resize_bilinear_kernel, grid, block, 0, vfi::as_stream(stream), x, x_bstride, residual, res_bstride,
+                           y, y_bstride, C, Hin, Win, Hout, Wout, align_corners, relu_input);
     return vfi::check_launch("vfi_resize_bilinear");
 }
 

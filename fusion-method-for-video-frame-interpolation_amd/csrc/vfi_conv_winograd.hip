@@ -325,73 +325,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
             const float *__restrict__ resp = (RES && !split_out && a.res) ? a.res + (size_t)it.n * a.res_bs : nullptr;
             float *__restrict__ yp = split_out ? a.ws + ((size_t)it.split * N + it.n) * a.Cout * HW : a.y + (size_t)it.n * a.y_bs;
             const int act = ACT >= 0 ? ACT : (split_out ? 0 : a.act);
-            const size_t pix = (size_t)gy0 * a.W + gxw;
-            // Fast path (wave-uniform): the tile lies inside the image and rows are 16-byte aligned.  Lane pairs (even /
-            // odd tile column) swap halves so that each lane stores ONE float4 per channel (the even lane the upper
-            // output row of both tiles, the odd lane the lower row): 8 stores per lane instead of 16.
+            const int co0 = it.nb * T::BN + 4 * k4;            // this lane's channel for (mb, j) = (0, 0)
+            const float *bias_l = lds + T::BIAS_OFF + (cseq & (T::NBUF - 1)) * 64 + 4 * k4;
+            auto outputs = [&](int mb, int j, float2 (&o)[2]) {     // the 2x2 outputs of (mb, j), before bias
+                float s0[4], s1[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0[c] = acc[mb][c][j] + acc[mb][4 + c][j] + acc[mb][8 + c][j];
+                    s1[c] = acc[mb][4 + c][j] - acc[mb][8 + c][j] - acc[mb][12 + c][j];
+                }
+                o[0] = make_float2(s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]);
+                o[1] = make_float2(s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
+            };
+            // Fast path (wave-uniform, straight-line): the tile lies inside the image and rows are 16-byte aligned.  Lane
+            // pairs (even / odd tile column) swap halves so that each lane stores ONE float4 per channel (the even lane
+            // the upper output row of both tiles, the odd lane the lower row): 8 stores per lane instead of 16.
             const bool vec4 = it.x0 + T::TW <= a.W && it.y0 + T::TH <= a.H && (a.W % 4 == 0) && ((reinterpret_cast<size_t>(yp) & 15) == 0) &&
                               (!resp || (reinterpret_cast<size_t>(resp) & 15) == 0);
-            const bool odd = n16 & 1;
-            const size_t pix4 = (size_t)(gy0 + (odd ? 1 : 0)) * a.W + (gxw & ~3);
-    #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const float *bl = lds + T::BIAS_OFF + (cseq & (T::NBUF - 1)) * 64 + mb * 16 + 4 * k4;
-                const float bv[4] = {split_out ? 0.0f : bl[0], split_out ? 0.0f : bl[1], split_out ? 0.0f : bl[2], split_out ? 0.0f : bl[3]};
-                float4 rv4[4];
-                float2 rv2[4][2];
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int co = min(it.nb * T::BN + mb * 16 + 4 * k4 + j, a.Cout - 1);
-                    rv4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    rv2[j][0] = rv2[j][1] = make_float2(0.0f, 0.0f);
-                    if (RES && resp) {
-                        if (vec4) {
-                            rv4[j] = *reinterpret_cast<const float4 *>(resp + (size_t)co * HW + pix4);
-                        } else if (gy0 < a.H && gxw < a.W) {
-    #pragma unroll
-                            for (int dy = 0; dy < 2; ++dy)
-                                if (gy0 + dy < a.H) {
-                                    const float *rp = resp + (size_t)co * HW + pix + dy * a.W;
-                                    rv2[j][dy].x = rp[0];
-                                    if (gxw + 1 < a.W) rv2[j][dy].y = rp[1];
-                                }
-                        }
-                    }
-                }
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int co = it.nb * T::BN + mb * 16 + 4 * k4 + j;
-                    float s0[4], s1[4];
-    #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        s0[c] = acc[mb][c][j] + acc[mb][4 + c][j] + acc[mb][8 + c][j];
-                        s1[c] = acc[mb][4 + c][j] - acc[mb][8 + c][j] - acc[mb][12 + c][j];
-                    }
-                    float2 o[2];
-                    o[0] = make_float2(s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]);
-                    o[1] = make_float2(s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
-                    if (vec4) {
+            if (vec4) {
+                const bool odd = n16 & 1;
+                const size_t off = (size_t)co0 * HW + (size_t)(gy0 + (odd ? 1 : 0)) * a.W + (gxw & ~3);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int dc = mb * 16 + j;            // channel step from co0
+                        float2 o[2];
+                        outputs(mb, j, o);
                         // quad_perm [1,0,3,2]: exchange with the neighbouring tile column
                         const float2 give = odd ? o[0] : o[1];
                         float2 got;
                         got.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0xB1, 0xf, 0xf, false));
                         got.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0xB1, 0xf, 0xf, false));
                         float4 q = odd ? make_float4(got.x, got.y, o[1].x, o[1].y) : make_float4(o[0].x, o[0].y, got.x, got.y);
-                        q.x = apply_act(q.x + bv[j], act) + rv4[j].x;
-                        q.y = apply_act(q.y + bv[j], act) + rv4[j].y;
-                        q.z = apply_act(q.z + bv[j], act) + rv4[j].z;
-                        q.w = apply_act(q.w + bv[j], act) + rv4[j].w;
-                        if (co < a.Cout) *reinterpret_cast<float4 *>(yp + (size_t)co * HW + pix4) = q;
-                    } else if (co < a.Cout && gy0 < a.H && gxw < a.W) {
-    #pragma unroll
+                        const float b = split_out ? 0.0f : bias_l[dc];
+                        q.x = apply_act(q.x + b, act); q.y = apply_act(q.y + b, act);
+                        q.z = apply_act(q.z + b, act); q.w = apply_act(q.w + b, act);
+                        if (co0 + dc < a.Cout) {
+                            if (RES && resp) {
+                                const float4 r = *reinterpret_cast<const float4 *>(resp + off + (size_t)dc * HW);
+                                q.x += r.x; q.y += r.y; q.z += r.z; q.w += r.w;
+                            }
+                            *reinterpret_cast<float4 *>(yp + off + (size_t)dc * HW) = q;
+                        }
+                    }
+            } else if (gy0 < a.H && gxw < a.W) {      // image border / unaligned rows: element-wise
+                const size_t off = (size_t)co0 * HW + (size_t)gy0 * a.W + gxw;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int dc = mb * 16 + j;
+                        if (co0 + dc >= a.Cout) continue;
+                        float2 o[2];
+                        outputs(mb, j, o);
+                        const float b = split_out ? 0.0f : bias_l[dc];
+#pragma unroll
                         for (int dy = 0; dy < 2; ++dy)
                             if (gy0 + dy < a.H) {
-                                float *op = yp + (size_t)co * HW + pix + dy * a.W;
-                                op[0] = apply_act(o[dy].x + bv[j], act) + rv2[j][dy].x;
-                                if (gxw + 1 < a.W) op[1] = apply_act(o[dy].y + bv[j], act) + rv2[j][dy].y;
+                                const size_t e = off + (size_t)dc * HW + (size_t)dy * a.W;
+                                float vx = apply_act(o[dy].x + b, act), vy = apply_act(o[dy].y + b, act);
+                                if (RES && resp) {
+                                    vx += resp[e];
+                                    if (gxw + 1 < a.W) vy += resp[e + 1];
+                                }
+                                yp[e] = vx;
+                                if (gxw + 1 < a.W) yp[e + 1] = vy;
                             }
                     }
-                }
             }
             if (!more) break;
             cL = nL;
