@@ -301,20 +301,40 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const ConvArgs a) {
     }
 }
 
-// y = act(sum_s ws[s] + bias) + residual   (deterministic split-K reduction)
+// y = act(sum_s ws[s] + bias) + residual   (deterministic split-K reduction: fixed summation order)
+// grid: x over the plane's pixels (VEC per thread), y = output channel, z = sample.
+template <int VEC>
 __global__ void conv2d_splitk_reduce_kernel(const float *__restrict__ ws, int splits, const float *__restrict__ bias,
                                             const float *__restrict__ res, long long res_bs, float *__restrict__ y,
-                                            long long y_bs, int N, int Cout, int HW, int act) {
-    const long long per = (long long)Cout * HW, total = (long long)N * per;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long e = i % per;
-        const int n = i / per, co = e / HW;
-        float v = 0.0f;
-        for (int sidx = 0; sidx < splits; ++sidx) v += ws[(size_t)sidx * total + i];
-        if (bias) v += bias[co];
-        v = apply_act(v, act);
-        if (res) v += res[(size_t)n * res_bs + e];
-        y[(size_t)n * y_bs + e] = v;
+                                            long long y_bs, int Cout, int HW, int act) {
+    const int p = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (p >= HW) return;
+    const int co = blockIdx.y, n = blockIdx.z;
+    const size_t e = (size_t)co * HW + p, total = (size_t)gridDim.z * Cout * HW;
+    const float *w = ws + (size_t)n * Cout * HW + e;
+    float v[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = 0.0f;
+    for (int sidx = 0; sidx < splits; ++sidx, w += total) {
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(w);
+            v[0] += t.x; v[1 % VEC] += t.y; v[2 % VEC] += t.z; v[3 % VEC] += t.w;
+        } else {
+            v[0] += w[0];
+        }
+    }
+    const float b = bias ? bias[co] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = apply_act(v[k] + b, act);
+    if (VEC == 4) {
+        if (res) {
+            const float4 r = *reinterpret_cast<const float4 *>(res + (size_t)n * res_bs + e);
+            v[0] += r.x; v[1 % VEC] += r.y; v[2 % VEC] += r.z; v[3 % VEC] += r.w;
+        }
+        *reinterpret_cast<float4 *>(y + (size_t)n * y_bs + e) = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
+    } else {
+        if (res) v[0] += res[(size_t)n * res_bs + e];
+        y[(size_t)n * y_bs + e] = v[0];
     }
 }
 
@@ -373,10 +393,16 @@ int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
 }  // namespace
 
 void vfi::conv::launch_splitk_reduce(const ConvArgs &b, int N, hipStream_t s) {
-    const long long tot = (long long)N * b.Cout * b.H * b.W;
-    const int rb = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
-    hipLaunchKernelGGL(conv2d_splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, b.ws, b.splits, b.bias, b.res, b.res_bs,
-                       b.y, b.y_bs, N, b.Cout, b.H * b.W, b.act);
+    const int HW = b.H * b.W;
+    const bool vec = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(b.y) & 15u) == 0 && b.y_bs % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(b.ws) & 15u) == 0 &&
+                     (!b.res || ((reinterpret_cast<uintptr_t>(b.res) & 15u) == 0 && b.res_bs % 4 == 0));
+    if (vec)
+        hipLaunchKernelGGL(conv2d_splitk_reduce_kernel<4>, dim3(vfi::ceil_div(HW / 4, 256), b.Cout, N), dim3(256), 0, s, b.ws,
+                           b.splits, b.bias, b.res, b.res_bs, b.y, b.y_bs, b.Cout, HW, b.act);
+    else
+        hipLaunchKernelGGL(conv2d_splitk_reduce_kernel<1>, dim3(vfi::ceil_div(HW, 256), b.Cout, N), dim3(256), 0, s, b.ws,
+                           b.splits, b.bias, b.res, b.res_bs, b.y, b.y_bs, b.Cout, HW, b.act);
 }
 
 extern "C" long long vfi_conv2d_packed_floats(int Cout, int Cin, int KS) {

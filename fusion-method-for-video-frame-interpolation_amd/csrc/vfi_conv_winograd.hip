@@ -463,12 +463,18 @@ int vfi::conv::launch_winograd(const ConvArgs &a, int N, hipStream_t s) {
     b.splits = 1;
     const int nchunks = vfi::ceil_div(a.Cin, T::CK);
     const long long out_floats = (long long)N * a.Cout * a.H * a.W;
+    // Cost model (microseconds, measured constants): rounds of resident workgroups x ~1.1 us per chunk of an item, plus
+    // the reduce pass that reads S partial tensors and writes one (~2.5 TB/s, + a launch).
     if (a.ws && nchunks >= 16 && b.wino_items < 4 * resident) {
-        auto cost = [&](int S) { return (double)(((long long)b.wino_items * S + resident - 1) / resident) / S; };
+        auto cost = [&](int S) {
+            const double rounds = (double)(((long long)b.wino_items * S + resident - 1) / resident);
+            const double reduce = S > 1 ? 4.0 + (double)(S + 1) * out_floats * 4.0 / 2.5e6 : 0.0;
+            return rounds * (1.1 * nchunks / S) + reduce;
+        };
         int best = 1;
         for (int S = 2; S <= 16; S *= 2)
-            if (nchunks / S >= 8 && out_floats * S <= a.ws_floats && cost(S) < cost(best) - 1e-9) best = S;
-        if (cost(best) <= 0.85 * cost(1)) b.splits = best;
+            if (nchunks / S >= 8 && out_floats * S <= a.ws_floats && cost(S) < cost(best)) best = S;
+        if (cost(best) <= 0.9 * cost(1)) b.splits = best;
     }
     const long long items = (long long)b.wino_items * b.splits;
     dim3 grid((unsigned)(items < resident ? items : resident));

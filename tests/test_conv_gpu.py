@@ -144,3 +144,63 @@ def test_conv_resized_prefix_matches_torch(n, c2, cd, hs, ws, h, w, device):
     pc = ops.PackedConv(wgt, b, device=device)
     out = ops.conv2d_resized_prefix(x.to(device), x2.to(device), pc, "reflect", "elu")
     assert (out.cpu() - ref).abs().max().item() <= 3e-5
+
+
+# The 3x3 layers run the Winograd F(2x2,3x3) kernel: interior tiles fetch 16-byte pieces, image-border tiles per element;
+# float4 stores need W % 4 == 0 and full tiles; long channel loops with few tiles are split over K; the activation is a
+# template parameter, a residual selects another instantiation.
+WINOGRAD_CASES = [
+    # n, cin, cout, h, w, pad, act, residual
+    (1, 64, 64, 24, 160, "zeros", "relu", False),      # 5 tile columns: interior (16-byte) and border tiles, full tiles
+    (2, 40, 96, 40, 128, "reflect", "elu", False),     # three channel blocks, reflect rows / columns
+    (1, 64, 64, 21, 131, "zeros", None, False),        # odd width: element-wise stores, ragged last tile
+    (1, 30, 25, 33, 98, "reflect", "tanh", False),     # W % 4 = 2, channel tails on both sides
+    (3, 64, 64, 16, 96, "reflect", "elu", True),       # residual instantiation (PhaseNet block)
+    (1, 16, 32, 16, 64, "zeros", "sigmoid", True),
+    (1, 512, 512, 12, 20, "zeros", "relu", False),     # split-K range (few tiles, 128 chunks)
+    (2, 256, 128, 9, 40, "reflect", None, False),
+    (1, 4, 32, 8, 32, "zeros", None, False),           # a single chunk per item
+    (1, 3, 3, 2, 2, "reflect", None, False),           # smallest reflect-padded image
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,pad,act,residual", WINOGRAD_CASES)
+def test_winograd_conv_matches_torch_cpu(n, cin, cout, h, w, pad, act, residual, device):
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + w)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wgt = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    res = torch.randn((n, cout, h, w), generator=g) if residual else None
+    ref = _ref(x.double(), wgt.double(), b.double(), 3, pad, act, None if res is None else res.double()).float()
+    pc = ops.PackedConv(wgt, b, device=device)
+    out = ops.conv2d(x.to(device), pc, pad, act, residual=None if res is None else res.to(device))
+    torch.cuda.synchronize()
+    # fp32 Winograd: the transforms add a few roundings to the direct sum (values are O(1))
+    assert (out.cpu() - ref).abs().max().item() <= 3e-5
+
+
+def test_winograd_conv_channel_slices_and_batch_strides(device):
+    # input and output are channel slices of wider tensors (PhaseNet's concatenated block inputs): only the batch
+    # stride is free; what lies outside the slices must stay untouched
+    g = torch.Generator().manual_seed(5)
+    big_in = torch.randn((2, 80, 16, 96), generator=g).to(device)
+    big_out = torch.full((2, 100, 16, 96), 7.0, device=device)
+    wgt = torch.randn((48, 40, 3, 3), generator=g) / 19.0
+    b = torch.randn((48,), generator=g) * 0.1
+    pc = ops.PackedConv(wgt, b, device=device)
+    ops.conv2d(big_in[:, 24:64], pc, "reflect", "relu", out=big_out[:, 20:68])
+    torch.cuda.synchronize()
+    ref = _ref(big_in[:, 24:64].cpu().double(), wgt.double(), b.double(), 3, "reflect", "relu").float()
+    assert (big_out[:, 20:68].cpu() - ref).abs().max().item() <= 3e-5
+    assert (big_out[:, :20] == 7.0).all() and (big_out[:, 68:] == 7.0).all()
+
+
+def test_winograd_conv_is_deterministic(device):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((2, 64, 40, 160), generator=g).to(device)
+    wgt = torch.randn((64, 64, 3, 3), generator=g) / 24.0
+    pc = ops.PackedConv(wgt, torch.zeros(64), device=device)
+    first = ops.conv2d(x, pc, "zeros", "relu").clone()
+    for _ in range(5):
+        ops.conv2d(torch.randn_like(x), pc, "zeros", None)          # other data through the same kernel in between
+        assert torch.equal(ops.conv2d(x, pc, "zeros", "relu"), first)
