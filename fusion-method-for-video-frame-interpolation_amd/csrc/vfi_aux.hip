@@ -133,6 +133,74 @@ __global__ __launch_bounds__(256) void resize_bilinear_vec4_kernel(const float *
     *reinterpret_cast<float4 *>(y + (size_t)n * y_bs + o) = v;
 }
 
+// Up-scaling (source step <= 1 in both directions): a workgroup stages the source window of a 16-row x 256-column
+// output tile in LDS with coalesced loads (each source element is fetched once per tile instead of once per output
+// that uses it); every thread writes four groups of 4 consecutive columns (VEC: as float4 -- rows 16-byte aligned).
+// Same arithmetic as above.
+constexpr int kRsTileY = 16, kRsTileX = 256, kRsMaxRows = kRsTileY + 2, kRsMaxCols = kRsTileX + 2;
+template <bool VEC>
+__global__ __launch_bounds__(256) void resize_bilinear_tile_kernel(const float *__restrict__ x, long long x_bs,
+                                                                   const float *__restrict__ res, long long res_bs,
+                                                                   float *__restrict__ y, long long y_bs, int C, int Hi, int Wi,
+                                                                   int Ho, int Wo, int align_corners, int relu_in) {
+    __shared__ float tile[kRsMaxRows][kRsMaxCols + 2];
+    const int X0 = blockIdx.x * kRsTileX, Y0 = blockIdx.y * kRsTileY;
+    const int n = blockIdx.z / C, c = blockIdx.z - n * C;
+    const float sy = align_corners ? (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f) : (float)Hi / (float)Ho;
+    const float sx = align_corners ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f) : (float)Wi / (float)Wo;
+    auto src_y = [&](int yo) { return align_corners ? sy * yo : fmaxf(sy * (yo + 0.5f) - 0.5f, 0.0f); };
+    auto src_x = [&](int xo) { return align_corners ? sx * xo : fmaxf(sx * (xo + 0.5f) - 0.5f, 0.0f); };
+    const int ylo = min((int)src_y(Y0), Hi - 1), yhi = min(min((int)src_y(min(Y0 + kRsTileY - 1, Ho - 1)), Hi - 1) + 1, Hi - 1);
+    const int xlo = min((int)src_x(X0), Wi - 1), xhi = min(min((int)src_x(min(X0 + kRsTileX - 1, Wo - 1)), Wi - 1) + 1, Wi - 1);
+    const int nrows = yhi - ylo + 1, ncols = xhi - xlo + 1;          // <= kRsMaxRows x kRsMaxCols (host checks the scale)
+    const float *p = x + (size_t)n * x_bs + (size_t)c * Hi * Wi;
+    for (int r = threadIdx.x >> 6; r < nrows; r += 4)
+        for (int q = threadIdx.x & 63; q < ncols; q += 64) {
+            const float v = p[(size_t)(ylo + r) * Wi + xlo + q];
+            tile[r][q] = relu_in ? fmaxf(v, 0.0f) : v;
+        }
+    __syncthreads();
+    const int xo0 = X0 + 4 * (threadIdx.x & 63);
+    if (xo0 >= Wo) return;
+    int x0[4], x1[4];
+    float lx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float fx = src_x(xo0 + k);
+        const int xs = min((int)fx, Wi - 1);
+        lx[k] = fx - (float)xs;
+        x0[k] = xs - xlo;
+        x1[k] = min(xs + 1, Wi - 1) - xlo;
+    }
+#pragma unroll
+    for (int rr = 0; rr < kRsTileY / 4; ++rr) {
+        const int yo = Y0 + (threadIdx.x >> 6) + 4 * rr;
+        if (yo >= Ho) break;
+        const float fy = src_y(yo);
+        const int ys = min((int)fy, Hi - 1);
+        const float ly = fy - (float)ys;
+        const float *t0 = tile[ys - ylo], *t1 = tile[min(ys + 1, Hi - 1) - ylo];
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            out[k] = (1.0f - ly) * ((1.0f - lx[k]) * t0[x0[k]] + lx[k] * t0[x1[k]]) +
+                     ly * ((1.0f - lx[k]) * t1[x0[k]] + lx[k] * t1[x1[k]]);
+        const size_t o = ((size_t)c * Ho + yo) * Wo + xo0;
+        if (VEC) {
+            float4 v = make_float4(out[0], out[1], out[2], out[3]);
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4 *>(res + (size_t)n * res_bs + o);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            *reinterpret_cast<float4 *>(y + (size_t)n * y_bs + o) = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (xo0 + k < Wo) y[(size_t)n * y_bs + o + k] = out[k] + (res ? res[(size_t)n * res_bs + o + k] : 0.0f);
+        }
+    }
+}
+
 // ---- single-output-channel `Upsample(x2, align_corners=True) -> Conv2d(C, 1, 3, padding=1)` tail ------------------
 // (Subnet_occlusion: fusion_adacofnet.py:68-70).  Both maps are linear, so conv(U(x)) = sum_t shift_t(U(m_t)) with
 // m_t = sum_c w[c][t] x_c a 1x1 convolution at LOW resolution (done by vfi_conv2d).  This kernel finishes:
@@ -310,7 +378,15 @@ extern "C" int vfi_resize_bilinear(const float *x, long long x_bstride, const fl
                      (!residual || ((reinterpret_cast<uintptr_t>(residual) & 15u) == 0 && res_bstride % 4 == 0));
     VFI_REQUIRE((long long)N * C <= 65535, VFI_ERR_UNSUPPORTED, "vfi_resize_bilinear: N*C = %lld planes", (long long)N * C);
     const dim3 block(64, 4), grid(ceil_div(vec ? Wout / 4 : Wout, 64), ceil_div(Hout, 4), N * C);
-    if (vec)
+    if (Hin <= Hout && Win <= Wout && Hout >= kRsTileY && Wout >= 64) {      // up-scaling: LDS-staged tiles
+        const dim3 tgrid(ceil_div(Wout, kRsTileX), ceil_div(Hout, kRsTileY), N * C);
+        if (vec)
+            hipLaunchKernelGGL(resize_bilinear_tile_kernel<true>, tgrid, dim3(256), 0, vfi::as_stream(stream), x, x_bstride, residual,
+                               res_bstride, y, y_bstride, C, Hin, Win, Hout, Wout, align_corners, relu_input);
+        else
+            hipLaunchKernelGGL(resize_bilinear_tile_kernel<false>, tgrid, dim3(256), 0, vfi::as_stream(stream), x, x_bstride, residual,
+                               res_bstride, y, y_bstride, C, Hin, Win, Hout, Wout, align_corners, relu_input);
+    } else if (vec)
         hipLaunchKernelGGL(resize_bilinear_vec4_kernel, grid, block, 0, vfi::as_stream(stream), x, x_bstride, residual,
                            res_bstride, y, y_bstride, C, Hin, Win, Hout, Wout, align_corners, relu_input);
     else
