@@ -106,8 +106,9 @@ typedef enum vfi_act {
 
 typedef enum vfi_pad { VFI_PAD_ZERO = 0, VFI_PAD_REFLECT = 1 } vfi_pad;
 
-/* Number of floats of the packed weight buffer for an (Cout, Cin, KS, KS) filter bank
- * (layout [round_up(Cin,8)][KS*KS][round_up(Cout,32)], zero filled); -1 on bad arguments. */
+/* Number of floats of the packed weight buffer for an (Cout, Cin, KS, KS) filter bank, -1 on bad arguments.
+ * The buffer is opaque to the caller: [round_up(Cin,8)][KS*KS][round_up(Cout,32)] (zero filled) and, for KS = 3,
+ * the Winograd F(2x2,3x3) transformed weights G g G^T as [round_up(Cin,8)][4][round_up(Cout,32)][4] behind it. */
 long long vfi_conv2d_packed_floats(int Cout, int Cin, int KS);
 
 /* Packs torch-layout (Cout, Cin, KS, KS) weights once at model-load time.  `scale` (Cout) or NULL
@@ -120,6 +121,8 @@ int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int 
  * Replaces every nn.Conv2d (+ following BatchNorm / ReLU / ELU / Tanh / Sigmoid, + the additive U-Net
  * skip) on the path: reference src/phase_net/phase_net.py:190-200, src/fusion_net/fusion_adacofnet.py:18-155,
  * src/fusion_net/fusion_net.py:24-41,56-69.
+ * KS = 3 runs Winograd F(2x2,3x3) on the fp32 matrix cores (same result up to fp32 rounding of the transforms:
+ * <= 3e-5 on O(1) data; VFI_CONV_WINOGRAD=0 in the environment selects the direct kernel), KS = 1 / 5 the direct one.
  *   x        (N, Cin, H, W); consecutive samples are x_bstride floats apart, so x may be a channel
  *            slice of a wider tensor (no concat / split copies)
  *   residual NULL or (N, Cout, H, W) with stride res_bstride, added AFTER the activation
