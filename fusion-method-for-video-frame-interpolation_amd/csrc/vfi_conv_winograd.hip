@@ -47,9 +47,12 @@ struct WinoTile {
     static constexpr int BUF = IN_FLOATS + W_FLOATS;      // 16 KiB
     static constexpr int NBUF = 4;
     static constexpr int MIN_LOADS = IN_X4 + W_INSTR;     // fewest DMA instructions a chunk issues per wave
-    static constexpr int BIAS_OFF = NBUF * BUF;          // NBUF x 64 floats: the bias of the items in flight
-    static constexpr size_t LDS_BYTES = ((size_t)NBUF * BUF + NBUF * 64) * sizeof(float);
-    static_assert(IN_X1 * 256 <= IN_FLOATS && PLANE_S % 4 == 0 && ROWP % 4 == 0, "tile layout");
+    // the bias of every item that can be in flight: the DMA cursor runs up to NBUF chunks = up to NBUF (one-chunk)
+    // items ahead of the item whose epilogue reads its slot
+    static constexpr int BIAS_SLOTS = 8;
+    static constexpr int BIAS_OFF = NBUF * BUF;          // BIAS_SLOTS x 64 floats
+    static constexpr size_t LDS_BYTES = ((size_t)NBUF * BUF + BIAS_SLOTS * 64) * sizeof(float);
+    static_assert(IN_X1 * 256 <= IN_FLOATS && PLANE_S % 4 == 0 && ROWP % 4 == 0 && BIAS_SLOTS > NBUF, "tile layout");
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
         // earlier; a null / short bias reads as 0.)
         if (live && first && uni(wave) == 0) {
             const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? a.bias : a.x, a.bias ? (unsigned)a.Cout * 4u : 0u);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(lds + T::BIAS_OFF + (uni(iseq) & (T::NBUF - 1)) * 64),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(lds + T::BIAS_OFF + (uni(iseq) & (T::BIAS_SLOTS - 1)) * 64),
                                                      4, lane < T::BN ? (unsigned)(uni(inb) * T::BN + lane) * 4u : 0xffffffffu, 0, 0, 0);
         }
         ifirst = false;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
             float *__restrict__ yp = split_out ? a.ws + ((size_t)it.split * N + it.n) * a.Cout * HW : a.y + (size_t)it.n * a.y_bs;
             const int act = ACT >= 0 ? ACT : (split_out ? 0 : a.act);
             const int co0 = it.nb * T::BN + 4 * k4;            // this lane's channel for (mb, j) = (0, 0)
-            const float *bias_l = lds + T::BIAS_OFF + (cseq & (T::NBUF - 1)) * 64 + 4 * k4;
+            const float *bias_l = lds + T::BIAS_OFF + (cseq & (T::BIAS_SLOTS - 1)) * 64 + 4 * k4;
             auto outputs = [&](int mb, int j, float2 (&o)[2]) {     // the 2x2 outputs of (mb, j), before bias
                 float s0[4], s1[4];
 #pragma unroll

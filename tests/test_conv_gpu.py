@@ -204,3 +204,15 @@ def test_winograd_conv_is_deterministic(device):
     for _ in range(5):
         ops.conv2d(torch.randn_like(x), pc, "zeros", None)          # other data through the same kernel in between
         assert torch.equal(ops.conv2d(x, pc, "zeros", "relu"), first)
+
+
+def test_winograd_conv_one_chunk_items_keep_their_bias(device):
+    # Cin <= 4: every work item is a single chunk, so the DMA cursor runs several items (and their bias fetches) ahead
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((2, 3, 64, 256), generator=g)
+    wgt = torch.randn((96, 3, 3, 3), generator=g) / 5.0
+    b = torch.randn((96,), generator=g)
+    pc = ops.PackedConv(wgt, b, device=device)
+    out = ops.conv2d(x.to(device), pc, "zeros", None)
+    torch.cuda.synchronize()
+    assert (out.cpu() - _ref(x.double(), wgt.double(), b.double(), 3, "zeros", None).float()).abs().max().item() <= 3e-5
