@@ -315,8 +315,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(u23, v, 2);
         __builtin_amdgcn_sched_barrier(0);
+        // The non-MFMA stretch of a chunk (DMA requests, cursor, transform) runs at raised priority: the sooner this wave
+        // is back at its MFMAs, the less often both waves of a SIMD are away from the matrix pipe at once (+2 %).
+        __builtin_amdgcn_s_setprio(3);
         issue_next(cur_slot);          // its issue cost overlaps the matrix-core work queued above
         transform(d, v);
+        __builtin_amdgcn_s_setprio(0);
         const bool last_of_item = ch + 1 == ch_end;
         const int nL = last_of_item ? next_valid(cL + G) : cL;
         const bool more = nL < Ltotal;
