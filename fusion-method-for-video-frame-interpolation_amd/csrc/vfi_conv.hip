@@ -474,10 +474,11 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     // chunk requested before the epilogue): -8 % (per-tile setup + spills outweigh the saved dispatch gaps).
     // Pseudo-random within-chunk start offsets for the first-round workgroups (de-phasing chunk boundaries): 0 %.
     // MFMA pipe utilisation of this structure is 70-76 % (PMC) at ~2.18 GHz.
-    // 3x3: Winograd F(2x2,3x3) unless VFI_CONV_WINOGRAD=0 (tuning / A-B aid: the direct kernels stay built) or the
-    // sample's input exceeds the 32-bit byte range of a buffer descriptor
+    // 3x3: Winograd F(2x2,3x3) unless VFI_CONV_WINOGRAD=0 (tuning / A-B aid: the direct kernels stay built), the
+    // sample's input exceeds the 32-bit byte range of a buffer descriptor, or the work-item count a 32-bit index
     static const bool wino_on = !(getenv("VFI_CONV_WINOGRAD") && atoi(getenv("VFI_CONV_WINOGRAD")) == 0);
-    if (KS == 3 && wino_on && (long long)Cin * H * W * 4 < (1ll << 32)) {
+    const long long wino_work_items = (long long)a.tiles_x * vfi::ceil_div(H, 8) * N * (a.Cout_pad / 32) * 16;   // (x max. K split)
+    if (KS == 3 && wino_on && (long long)Cin * H * W * 4 < (1ll << 32) && wino_work_items < (1ll << 30)) {
         a.wp = packed_w + (size_t)a.Cin_pad * 9 * a.Cout_pad;
         return launch_winograd(a, N, s);
     }
