@@ -448,7 +448,7 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     a.H = H; a.W = W; a.tiles_x = vfi::ceil_div(W, 32);
     a.pad_mode = pad_mode; a.act = act;
     a.ws = workspace_floats > 0 ? workspace : nullptr; a.ws_floats = workspace ? workspace_floats : 0; a.splits = 1;
-    a.x2 = nullptr; a.x2_bs = 0; a.rsz_channels = 0; a.wino_tiles = 0; a.wino_items = 0; a.wino_batch = 0;
+    a.x2 = nullptr; a.x2_bs = 0; a.rsz_channels = 0; a.wino_tiles = 0; a.wino_items = 0; a.wino_batch = 0; a.wino_run = 1;
     a.Hs = H / 2; a.Ws = W / 2;
     a.ups_sy = H > 1 ? (float)(a.Hs - 1) / (float)(H - 1) : 0.0f;
     a.ups_sx = W > 1 ? (float)(a.Ws - 1) / (float)(W - 1) : 0.0f;

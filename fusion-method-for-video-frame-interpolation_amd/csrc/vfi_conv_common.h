@@ -22,7 +22,7 @@ struct ConvArgs {
     const float *x2;       // SRC = 2: tensor whose resize forms the first rsz_channels input channels
     long long x2_bs;
     int rsz_channels;      // multiple of CK
-    int wino_tiles, wino_items, wino_batch;   // Winograd kernel: spatial tiles per sample; work items per K split; N
+    int wino_tiles, wino_items, wino_batch, wino_run;   // Winograd kernel: spatial tiles per sample; work items per K split; N; tiles per XCD run
     int Hs, Ws;    // UPS kernels: size of the low-resolution source x (H = 2*Hs, W = 2*Ws)
     float ups_sy, ups_sx;   // (Hs-1)/(H-1), (Ws-1)/(W-1): torch bilinear, align_corners=True
 };

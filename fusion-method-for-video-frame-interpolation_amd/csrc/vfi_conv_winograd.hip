@@ -80,8 +80,15 @@ __device__ __forceinline__ Item decode_item(const ConvArgs &a, int L) {
     const int cb = a.Cout_pad / T::BN;
     it.split = L / a.wino_items;
     const int Lr = L - it.split * a.wino_items;
-    const int tl = (Lr / (8 * cb)) * 8 + (Lr & 7);         // see the header comment: XCD-aware order
-    it.nb = (Lr >> 3) % cb;
+    // XCD-aware order.  Workgroup L runs on XCD L % 8 (own L2 each).  Consecutive slots of one XCD take the channel
+    // blocks of the SAME spatial tile, then the next tile of a run of `wino_run` horizontally adjacent tiles: the input
+    // tile is fetched once for all channel blocks, and the 128-byte lines a tile shares with its left / right neighbours
+    // (a tile is exactly one line wide, its halo touches both neighbouring lines) stay inside one L2 within a run
+    // (fabric reads of the 1080p 64->64 layers: 3.4 -> 1.5 GB by FETCH_SIZE).  Runs are dealt round-robin to the XCDs.
+    const int xcd = Lr & 7, q = Lr >> 3;
+    it.nb = q % cb;
+    const int tq = q / cb, run = a.wino_run;
+    const int tl = ((tq / run) * 8 + xcd) * run + tq % run;
     it.n = tl / a.wino_tiles;
     const int t = tl - it.n * a.wino_tiles;
     it.valid = it.n < a.wino_batch;
@@ -464,7 +471,10 @@ int vfi::conv::launch_winograd(const ConvArgs &a, int N, hipStream_t s) {
     const int cb = a.Cout_pad / T::BN;
     b.wino_tiles = a.tiles_x * vfi::ceil_div(a.H, T::TH);
     b.wino_batch = N;
-    b.wino_items = round_up(b.wino_tiles * N, 8) * cb;
+    // run length of x-adjacent tiles per XCD: as long as every XCD still gets >= 32 runs (<= 3 % imbalance)
+    b.wino_run = 1;
+    while (b.wino_run < 8 && (long long)b.wino_tiles * N >= 256ll * 2 * b.wino_run) b.wino_run *= 2;
+    b.wino_items = round_up(b.wino_tiles * N, 8 * b.wino_run) * cb;
     // Split-K: few, long items (deep U-Net levels) leave most of the resident workgroups idle; splitting the channel
     // loop S ways makes S times as many items of 1/S the length (partial sums reduced deterministically afterwards).
     b.splits = 1;
