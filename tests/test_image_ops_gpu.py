@@ -70,7 +70,12 @@ def test_glue_ops(device):
 
 @pytest.mark.parametrize("hi,wi,ho,wo,ac,relu", [(9, 15, 12, 20, False, False), (12, 20, 17, 29, False, False),
                                                  (10, 12, 20, 24, True, False), (8, 12, 16, 24, False, True),
-                                                 (6, 11, 8, 15, False, False)])
+                                                 (6, 11, 8, 15, False, False),
+                                                 # >= 16 x 64 outputs, up-scaling: the LDS-staged tile kernel (float4 rows /
+                                                 # ragged rows, several tiles in both directions, relu + residual)
+                                                 (40, 70, 80, 140, True, False), (33, 45, 47, 66, False, False),
+                                                 (20, 40, 40, 80, False, True), (100, 300, 200, 600, True, True),
+                                                 (54, 96, 77, 135, False, False), (16, 64, 16, 64, True, False)])
 def test_resize_bilinear_matches_torch(hi, wi, ho, wo, ac, relu, device):
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(hi * wo)
