@@ -159,6 +159,7 @@ WINOGRAD_CASES = [
     (1, 16, 32, 16, 64, "zeros", "sigmoid", True),
     (1, 512, 512, 12, 20, "zeros", "relu", False),     # split-K range (few tiles, 128 chunks)
     (2, 256, 128, 9, 40, "reflect", None, False),
+    (1, 512, 96, 9, 15, "zeros", "elu", False),        # split-K with H*W % 4 != 0: element-wise reduce kernel
     (1, 4, 32, 8, 32, "zeros", None, False),           # a single chunk per item
     (1, 3, 3, 2, 2, "reflect", None, False),           # smallest reflect-padded image
 ]
