@@ -18,6 +18,7 @@ from PIL import Image  # noqa: E402
 dev = torch.device("cuda:0")
 runners, _ = bench.build_runner(dev, 2)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
+IO = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 with tempfile.TemporaryDirectory() as td:
     src, dst = os.path.join(td, "in"), os.path.join(td, "out")
     os.makedirs(src)
@@ -26,11 +27,11 @@ with tempfile.TemporaryDirectory() as td:
     for i in range(n):
         Image.fromarray(np.roll(base, 3 * i, axis=1)).save(os.path.join(src, f"{i:03d}.png"))
     args = types.SimpleNamespace(gpu_id=0, input_video=src, output_video=dst, index_from=0, zpad=3)
-    iv.interpolate_video(args, runners=runners, io_threads=8)          # warm-up (plans, packed weights)
+    iv.interpolate_video(args, runners=runners, io_threads=IO)          # warm-up (plans, packed weights)
     for f in os.listdir(dst):
         os.remove(os.path.join(dst, f))
     t0 = time.perf_counter()
-    done = iv.interpolate_video(args, runners=runners, io_threads=8)
+    done = iv.interpolate_video(args, runners=runners, io_threads=IO)
     dt = time.perf_counter() - t0
     print(f"clip of {n} frames at 1920x1080 from/to PNG: {done} interpolated frames in {dt:.2f} s = {done/dt:.2f} frames/s "
-          f"(8 I/O threads, 2 frames in flight)")
+          f"({IO} I/O threads, 2 frames in flight)")
