@@ -31,6 +31,16 @@ inline hipStream_t as_stream(vfi_stream_t s) { return reinterpret_cast<hipStream
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Per-device one-time setup (hipFuncSetAttribute applies to the current device only; the CU count is a device
+// property): caches are indexed by the calling thread's current device, so a process that drives several GPUs
+// sets every one of them up.  Values are idempotent: racing threads store the same thing.
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace vfi

@@ -360,12 +360,13 @@ __global__ void conv2d_pack_kernel(const float *__restrict__ w, const float *__r
 template <int KS, int CK, int NT, int UPS = 0, int RW = 2>
 int launch_conv(const ConvArgs &a, int N, hipStream_t s) {
     using T = ConvTile<KS, CK, NT, RW>;
-    static bool attr_done = false;  // idempotent; racing threads set the same value
-    if (!attr_done) {
+    static bool attr_done[vfi::kMaxDevices] = {};  // per device, idempotent
+    const int dev = vfi::current_device();
+    if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_mfma_kernel<KS, CK, NT, UPS, RW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
         if (e != hipSuccess) return vfi::fail(VFI_ERR_LAUNCH, "vfi_conv2d: set LDS size: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     const int tiles_y = vfi::ceil_div(a.H, T::TH);
     const long long blocks = (long long)a.tiles_x * tiles_y * (a.Cout_pad / T::BN) * N;

@@ -451,7 +451,8 @@ void vfi::conv::launch_pack_winograd(const float *w_oihw, const float *scale, fl
 
 int vfi::conv::launch_winograd(const ConvArgs &a, int N, hipStream_t s) {
     using T = WinoTile;
-    static int resident = 0;        // persistent grid: 2 workgroups per CU (idempotent; racing threads set the same value)
+    static int resident_dev[vfi::kMaxDevices] = {};   // persistent grid: 2 workgroups per CU; per device, idempotent
+    int &resident = resident_dev[vfi::current_device()];
     if (!resident) {
         hipError_t e = hipSuccess;
         for (const void *k : {reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 0>),

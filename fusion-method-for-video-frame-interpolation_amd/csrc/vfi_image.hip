@@ -354,7 +354,30 @@ extern "C" int vfi_mul(const float *a, const float *b, float *out, long long cou
 }
 
 namespace {
+// F.avg_pool2d(kernel_size=f): stride f, floor output size; accumulation in the row-major order of the window
+__global__ void avg_pool_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int H, int W, int f) {
+    const int Ho = H / f, Wo = W / f;
+    const long long total = (long long)planes * Ho * Wo;
+    const float inv = 1.0f / (float)(f * f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+        const long long p = i / ((long long)Wo * Ho);
+        const float *src = x + (p * H + (long long)yo * f) * W + (long long)xo * f;
+        float acc = 0.0f;
+        for (int dy = 0; dy < f; ++dy)
+            for (int dx = 0; dx < f; ++dx) acc += src[(long long)dy * W + dx];
+        y[i] = acc * inv;
+    }
+}
 }  // namespace
+
+extern "C" int vfi_avg_pool(const float *x, float *y, int planes, int H, int W, int f, vfi_stream_t stream) {
+    VFI_REQUIRE(x && y, VFI_ERR_INVALID_ARG, "vfi_avg_pool: null pointer");
+    VFI_REQUIRE(planes > 0 && f >= 1 && H >= f && W >= f, VFI_ERR_INVALID_ARG, "vfi_avg_pool: bad sizes");
+    const long long total = (long long)planes * (H / f) * (W / f);
+    hipLaunchKernelGGL(avg_pool_kernel, dim3(blocks_1d(total)), dim3(256), 0, vfi::as_stream(stream), x, y, planes, H, W, f);
+    return vfi::check_launch("vfi_avg_pool");
+}
 
 extern "C" int vfi_rgb2lab(const float *rgb, float *lab, int N, int HW, vfi_stream_t stream) {
     VFI_REQUIRE(rgb && lab, VFI_ERR_INVALID_ARG, "vfi_rgb2lab: null pointer");
@@ -411,7 +434,8 @@ extern "C" int vfi_median_filter(const float *x, float *y, int N, int H, int W, 
     VFI_REQUIRE(N <= 65535, VFI_ERR_UNSUPPORTED, "vfi_median_filter: batch");
     if ((kRkTW + size - 1) * (kRkTH + size - 1) <= kRkN && size >= 2) {
         constexpr size_t lds = kRkN * 4 + kRkN * 2 * 2 + (size_t)kRkTH * kRkWords * 4;   // 128 KiB
-        static bool attr_done = false;
+        static bool attr_done_dev[vfi::kMaxDevices] = {};  // per device, idempotent
+        bool &attr_done = attr_done_dev[vfi::current_device()];
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(median_rank_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vfi_diff_sums": [c_f, c_f, c_l, c_f, c_f, c_s],
     "vfi_ssim_sum": [c_f] * 5 + [c_i] * 4 + [c_fl, c_fl, c_f, c_f, c_s],
     "vfi_mul": [c_f, c_f, c_f, c_l, c_s],
+    "vfi_avg_pool": [c_f, c_f, c_i, c_i, c_i, c_i, c_s],
     "vfi_pyr_plan_create": [c_i, c_i, c_i, c_i, c_d, c_i, ctypes.POINTER(ctypes.c_void_p)],
     "vfi_pyr_plan_destroy": [ctypes.c_void_p],
     "vfi_pyr_plan_level_size": [ctypes.c_void_p, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
@@ -112,6 +113,17 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+def check_device(t, name="tensor"):
+    """Every call enqueues on the CURRENT device's current stream (stream_ptr): a tensor that lives on another GPU
+    would be handed to the wrong device's queue.  One process drives one GPU; a caller that
+    really wants a second device in the same process wraps the call in `torch.cuda.device(t.device)`."""
+    import torch
+    cur = torch.cuda.current_device()
+    if t.device.index != cur:
+        raise VfiLibraryError(f"{name} is on {t.device} but the current HIP device is cuda:{cur}; "
+                              f"wrap the call in torch.cuda.device({t.device.index})")
+
+
 def dptr(t, name="tensor", dtype=None):
     """Device address of a dense HIP tensor (None -> NULL)."""
     import torch
@@ -119,6 +131,7 @@ def dptr(t, name="tensor", dtype=None):
         return None
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise VfiLibraryError(f"{name} must be a tensor on a HIP device (vfi_amd has no CPU path)")
+    check_device(t, name)
     if t.dtype != (dtype or torch.float32):
         raise VfiLibraryError(f"{name} must be {dtype or torch.float32}, got {t.dtype}")
     if not t.is_contiguous():

@@ -7,7 +7,8 @@
     of the difference, evaluate_image.py:25-26);
   * ssim  -- piq.ssim defaults (11-tap Gaussian sigma 1.5, valid region, k1=0.01, k2=0.03, average-pool downsample by
     max(1, round(min(H,W)/256))): restated from piq's published formula (piq is absent here: PARITY UNPINNED);
-  * lpips -- needs pretrained VGG weights that are not available offline: returned as NaN.
+  * lpips -- needs piq's pretrained VGG16 + linear-head weights, which exist neither in the reference tree nor in
+    this image (no network): the column is NaN, and vfi_amd.evaluation.evaluate aggregates NaN-aware.
 All reductions are deterministic (fixed-order double accumulation in libvfi_hip.so)."""
 import math
 
@@ -35,11 +36,13 @@ def ssim(x, y, kernel_size=11, kernel_sigma=1.5, k1=0.01, k2=0.03, downsample=Tr
     """x, y: (C,H,W) in [0,1] on the device."""
     c, h, w = x.shape
     f = max(1, round(min(h, w) / 256))
-    if f > 1 and downsample:                                   # piq: F.avg_pool2d(kernel_size=f); f=2 is our pool2 kernel
-        if f != 2:
-            raise ops.VfiLibraryError(f"ssim: downsample factor {f} not implemented (images up to 640 px min side)")
-        x = ops.pool2(x.unsqueeze(0).contiguous(), False)[0]
-        y = ops.pool2(y.unsqueeze(0).contiguous(), False)[0]
+    if f > 1 and downsample:                                   # piq: F.avg_pool2d(kernel_size=f)
+        def pool(t):
+            t = t.contiguous()
+            o = torch.empty((c, h // f, w // f), dtype=torch.float32, device=t.device)
+            _lib.call("vfi_avg_pool", _lib.dptr(t, "x"), o.data_ptr(), c, h, w, f, _lib.stream_ptr())
+            return o
+        x, y = pool(x), pool(y)
         c, h, w = x.shape
     x, y = x.contiguous(), y.contiguous()
     n = x.numel()

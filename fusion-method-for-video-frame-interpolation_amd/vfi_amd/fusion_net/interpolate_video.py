@@ -132,7 +132,9 @@ def interpolate_video(args, runners=None, loaded_adacof_model=None, loaded_fusio
         decoded.pop(i - 1, None)
         while len(writes) > 8 * len(runners):    # bound the pinned buffers / queued encodes
             writes.pop(0).result()
-    if hi == n_frames - 1 and n_frames > 0:      # last original frame (interpolate_video.py:116-119), by its owner rank
+    # last original frame (interpolate_video.py:116-119): written by the ONE rank that owns the last pair (ranks whose
+    # shard is empty -- world > pairs -- also end at hi == n_frames - 1 and must not write it again)
+    if hi == n_frames - 1 and n_frames > 0 and (hi > lo or (n_frames == 1 and rank == 0)):
         last = decoded[hi].result() if hi in decoded else _decode(frame_path(base, hi + index_from, zpad), dim)
         writes.append(pool.submit(_encode, last, frame_path(out_dir, (n_frames - 1) * 2 + index_from, zpad)))
     for w in writes:

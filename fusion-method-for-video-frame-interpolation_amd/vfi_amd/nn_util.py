@@ -81,10 +81,22 @@ class PackedModule(nn.Module):
         return super().train(False)
 
     def packed(self):
+        """Packed weights, built on first use.  The pack kernels are enqueued on the CALLER's current stream, and the
+        modules are shared by frames in flight on other streams (bench.py, interpolate_video): the build therefore ends
+        with a host wait for that stream, once per parameter load, so every later caller on ANY stream finds finished
+        buffers (no per-call events; never happens inside a hipGraph capture because a captured frame is warmed up
+        first).  `prepare()` is the explicit spelling for callers that want the cost up front."""
         if self._packed is None:
             with torch.no_grad():
                 self._packed = self._build_packed()
+            dev = next(self.parameters()).device
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()
         return self._packed
+
+    def prepare(self):
+        self.packed()
+        return self
 
     def _build_packed(self):  # pragma: no cover
         raise NotImplementedError

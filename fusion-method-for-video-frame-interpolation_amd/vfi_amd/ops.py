@@ -21,6 +21,7 @@ def _slice_ptr(t, name):
         raise VfiLibraryError(f"{name} must be a tensor on a HIP device (vfi_amd has no CPU path)")
     if t.dtype != torch.float32 or t.dim() != 4:
         raise VfiLibraryError(f"{name} must be a 4-d float32 tensor")
+    _lib.check_device(t, name)
     n, c, h, w = t.shape
     sn, sc, sh, sw = t.stride()
     if not ((sw == 1 or w == 1) and (sh == w or h == 1) and (sc == h * w or c == 1)):

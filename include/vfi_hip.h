@@ -15,7 +15,12 @@
  *     stream).  Calls only enqueue work; none synchronises the device, allocates or
  *     frees device memory, so a sequence of calls can be captured into a hipGraph.
  *     Workspace is caller-provided or owned by an explicit plan object.
- *   - The library holds no global mutable state besides immutable per-plan tables.
+ *   - Process-wide state is limited to idempotent per-device launch setup (the dynamic-LDS
+ *     attribute of three kernels, the CU count), tuning switches read once from the
+ *     environment (VFI_CONV_WINOGRAD, VFI_ADACOF_VARIANT, VFI_ADACOF_MARGIN) and the
+ *     thread-local last-error string; everything else lives in explicit plan objects,
+ *     whose tables are immutable after creation and whose workspace belongs to ONE stream
+ *     at a time (frames in flight on different streams use different plans).
  *
  * Each declaration cites the reference interface it replaces (paths relative to the
  * reference repository root).
@@ -326,6 +331,10 @@ int vfi_ssim_sum(const float *mu_x, const float *mu_y, const float *e_xx, const 
 
 /* out = a * b elementwise. */
 int vfi_mul(const float *a, const float *b, float *out, long long count, vfi_stream_t stream);
+
+/* F.avg_pool2d(kernel_size=f) on `planes` dense (H,W) planes -> (H/f, W/f) (floor): the down-sampling step of piq.ssim
+ * (called at src/evaluation/evaluate_image.py:21) for images whose short side exceeds 384 px. */
+int vfi_avg_pool(const float *x, float *y, int planes, int H, int W, int f, vfi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -58,16 +58,21 @@ def point_op(im, y, x):
 class PyramidSpec:
     """All level geometry + masks for one (H, W, height, nbands, scale_factor)."""
 
-    def __init__(self, H, W, height, nbands=4, scale_factor=math.sqrt(2)):
+    def __init__(self, H, W, height, nbands=4, scale_factor=math.sqrt(2), size_rule="ceil", dc_rule="half"):
+        """size_rule / dc_rule select spec VARIANTS for tools/pyramid_spec_pin.py only (the functional pin of the
+        self-defined spec against the reference's trained phase_net.pt); the product implements ("ceil", "half")."""
         self.H, self.W, self.height, self.nbands, self.s = H, W, height, nbands, float(scale_factor)
         self.nlev = height - 2
         if self.nlev < 1:
             raise ValueError("height must be >= 3")
-        size = lambda d, k: int(math.ceil(d / self.s ** k - 1e-9))
+        rnd = {"ceil": lambda v: math.ceil(v - 1e-9), "floor": lambda v: math.floor(v + 1e-9),
+               "round": lambda v: math.floor(v + 0.5)}[size_rule]
+        size = lambda d, k: int(rnd(d / self.s ** k))
         self.sizes = [(size(H, k), size(W, k)) for k in range(self.nlev + 1)]   # [nlev] = low residual
         if min(self.sizes[-1]) < 2:
             raise ValueError(f"pyramid height {height} too large for {H}x{W}")
-        self.starts = [(H // 2 - h // 2, W // 2 - w // 2) for h, w in self.sizes]
+        dc = (lambda d: d // 2) if dc_rule == "half" else (lambda d: (d - 1) // 2)
+        self.starts = [(H // 2 - (dc(h) if h < H else h // 2), W // 2 - (dc(w) if w < W else w // 2)) for h, w in self.sizes]
         log_rad, angle = prepare_grid(H, W)
         xr, yr = rcos_fn(1, -0.5)
         yr = np.sqrt(yr)
@@ -151,13 +156,14 @@ def reconstruct(spec, coeff):
 class Pyramid:
     """Same surface as reference src/train/pyramid.py:20-46 (CPU, oracle)."""
 
-    def __init__(self, height, nbands=4, scale_factor=math.sqrt(2), device="cpu"):
+    def __init__(self, height, nbands=4, scale_factor=math.sqrt(2), device="cpu", **variant):
         self.height, self.nbands, self.scale_factor, self.device = height, nbands, scale_factor, device
+        self.variant = variant
         self._specs = {}
 
     def spec(self, h, w):
         if (h, w) not in self._specs:
-            self._specs[(h, w)] = PyramidSpec(h, w, self.height, self.nbands, self.scale_factor)
+            self._specs[(h, w)] = PyramidSpec(h, w, self.height, self.nbands, self.scale_factor, **self.variant)
         return self._specs[(h, w)]
 
     def filter(self, img):
