@@ -136,7 +136,7 @@ class FusionInterpolator:
 
 def build_models(args, device):
     """The model construction of interpolate_twoframe.py:88-103,139-145 / src/evaluation/evaluate.py:225-242."""
-    if hasattr(args, "loaded_adacof_model"):
+    if getattr(args, "loaded_adacof_model", None) is not None:
         adacof_model = args.loaded_adacof_model
     else:
         adacof_model = Model(SimpleNamespace(gpu_id=args.gpu_id, model=getattr(args, "adacof_model", DEFAULT_ADACOF_MODEL),
@@ -146,7 +146,7 @@ def build_models(args, device):
         ckpt = getattr(args, "adacof_checkpoint", None)
         if ckpt and os.path.exists(ckpt):
             adacof_model.load(torch.load(ckpt, map_location="cpu")["state_dict"])
-    if hasattr(args, "loaded_fusion_net"):
+    if getattr(args, "loaded_fusion_net", None) is not None:
         fusion_net = args.loaded_fusion_net
     else:
         fusion_net = FusionNet().to(device)
@@ -155,21 +155,42 @@ def build_models(args, device):
     return adacof_model, fusion_net
 
 
-_INTERPOLATORS = {}
+_INTERPOLATORS = {}      # key -> FusionInterpolator (holds its models), at most _MAX_INTERPOLATORS, least recently used first
+_MAX_INTERPOLATORS = 4
+
+
+def _interpolator_for(args, device):
+    """One FusionInterpolator (models + per-size pyramid plans, ~1 GB of workspace at 1080p) per model identity:
+    pre-loaded models (src/evaluation passes them, interpolate.py:78-79) are keyed by object; otherwise the key is the
+    set of checkpoint paths, so repeated file-based calls build the models and plans ONCE instead of once per call
+    (the reference rebuilds everything per frame, interpolate_twoframe.py:88-103,124-145).  Bounded LRU: an evicted
+    entry releases its plans."""
+    pn = getattr(args, "phase_net_checkpoint", "./src/phase_net/phase_net.pt")      # :134
+    if getattr(args, "loaded_adacof_model", None) is not None and getattr(args, "loaded_fusion_net", None) is not None:
+        key = ("loaded", id(args.loaded_adacof_model), id(args.loaded_fusion_net), pn, device.index)
+    else:
+        key = ("files", getattr(args, "adacof_model", DEFAULT_ADACOF_MODEL), getattr(args, "adacof_checkpoint", None),
+               getattr(args, "checkpoint", None), args.adacof_kernel_size, args.adacof_dilation, pn, device.index,
+               id(getattr(args, "loaded_adacof_model", None)), id(getattr(args, "loaded_fusion_net", None)))
+    runner = _INTERPOLATORS.pop(key, None)
+    if runner is None:
+        adacof_model, fusion_net = build_models(args, device)
+        state = torch.load(pn, map_location="cpu") if pn and os.path.exists(pn) else None
+        runner = FusionInterpolator(adacof_model, fusion_net, state, device)     # (keeps the models alive: ids stay unique)
+        while len(_INTERPOLATORS) >= _MAX_INTERPOLATORS:
+            _INTERPOLATORS.pop(next(iter(_INTERPOLATORS)))
+    _INTERPOLATORS[key] = runner                                                  # most recently used last
+    return runner
 
 
 def interp(args, high_level=False):
-    """File-based entry point with the reference's argument namespace (interpolate_twoframe.py:82-334)."""
+    """File-based entry point with the reference's argument namespace (interpolate_twoframe.py:82-334).
+    `high_level` (and `args.high_level`) is accepted and ignored, as in the reference: its `interp` never reads either
+    (the only `high_level` in its body is the DecompValues field, :289,307)."""
     from PIL import Image
     torch.cuda.set_device(args.gpu_id)
     device = torch.device("cuda:{}".format(args.gpu_id))
-    adacof_model, fusion_net = build_models(args, device)
-    key = (id(adacof_model), id(fusion_net))
-    if key not in _INTERPOLATORS:
-        pn = getattr(args, "phase_net_checkpoint", "./src/phase_net/phase_net.pt")      # :134
-        state = torch.load(pn, map_location="cpu") if pn and os.path.exists(pn) else None
-        _INTERPOLATORS[key] = FusionInterpolator(adacof_model, fusion_net, state, device)
-    runner = _INTERPOLATORS[key]
+    runner = _interpolator_for(args, device)
     img1 = crop_center(np.array(Image.open(args.first_frame)), args.dim, args.dim)       # :106-113
     img2 = crop_center(np.array(Image.open(args.second_frame)), args.dim, args.dim)
     to_t = lambda a: torch.as_tensor(a[..., :3]).permute(2, 0, 1).float().to(device) / 255

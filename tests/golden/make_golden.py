@@ -278,8 +278,60 @@ def gen_adacofnet():
         save("adacofnet_" + tag, **d)
 
 
+def gen_phasenet_only():
+    """BASELINE.json configs[0]: the PhaseNet-only flow of src/phase_net/interpolate_twoframe.py:62-104 at 256x256
+    (per colour channel: filter x2 -> get_concat_layers -> normalize_vals -> PhaseNet -> inv_filter), run with the
+    REFERENCE's own `Pyramid` adapter (src/train/pyramid.py), `get_concat_layers` (src/train/utils.py:19-44) and
+    `PhaseNet` (src/phase_net/phase_net.py).  The one stand-in is the absent third-party transform
+    `steerable.SCFpyr_PyTorch`, whose build() / reconstruct() are served by oracle/pyramid_cpu.py -- the same
+    substitution as the CUDA-only sampler in gen_adacofnet.  The Lab conversion (skimage, absent) stays outside: the
+    flow starts from Lab images the tests regenerate from seeds, so the fixture stores the output only."""
+    _placeholders()
+    nets, synth = _oracle()
+    from oracle import color_cpu, layout_cpu, pyramid_cpu
+
+    class OracleSCF:
+        def __init__(self, height, nbands, scale_factor, device):
+            self.height, self.nbands, self.scale_factor = height, nbands, scale_factor
+            self._specs = {}
+
+        def _spec(self, h, w):
+            if (h, w) not in self._specs:
+                self._specs[(h, w)] = pyramid_cpu.PyramidSpec(h, w, self.height, self.nbands, self.scale_factor)
+            return self._specs[(h, w)]
+
+        def build(self, x):
+            return pyramid_cpu.build(self._spec(*x.shape[-2:]), x[:, 0])
+
+        def reconstruct(self, coeff):
+            return pyramid_cpu.reconstruct(self._spec(*coeff[0].shape[-2:]), coeff)
+
+    import src.train.pyramid as rpyr
+    rpyr.SCFpyr_PyTorch = OracleSCF
+    from src.train.utils import get_concat_layers
+    from src.phase_net.phase_net import PhaseNet
+    h = w = 256
+    f0, _, f2 = (torch.from_numpy(x) for x in synth.translating_pair(4, h, w))
+    img_1, img_2 = color_cpu.rgb2lab_single(f0), color_cpu.rgb2lab_single(f2)
+    pyr = rpyr.Pyramid(height=layout_cpu.calc_pyr_height(h, w), nbands=4, scale_factor=np.sqrt(2), device="cpu")
+    assert pyr.height == 12
+    net = PhaseNet(pyr, torch.device("cpu"))
+    print(net.load_state_dict(nets.phasenet_random_state_dict(seed=1)))
+    net.eval()
+    result = []
+    for c in range(3):                                                   # interpolate_twoframe.py:82-104
+        vals_1 = pyr.filter(img_1[c].unsqueeze(0))
+        vals_2 = pyr.filter(img_2[c].unsqueeze(0))
+        vals_normalized = net.normalize_vals(get_concat_layers(pyr, vals_1, vals_2))
+        with torch.no_grad():
+            vals_r = net(vals_normalized)
+        result.append(pyr.inv_filter(vals_r).detach())
+    lab_pred = torch.cat(result, 0)
+    save("phasenet_only_256", pair_seed=4, weight_seed=1, h=h, w=w, height=pyr.height, lab_pred=lab_pred.numpy())
+
+
 GENERATORS = {"adacof": gen_adacof, "phasenet": gen_phasenet, "layout": gen_layout,
-              "fusionnet": gen_fusionnet, "adacofnet": gen_adacofnet}
+              "fusionnet": gen_fusionnet, "adacofnet": gen_adacofnet, "phasenet_only": gen_phasenet_only}
 
 
 def main():

@@ -75,3 +75,59 @@ def test_interpolate_video_directory_on_gpu(tmp_path, device):
     ref_u8 = ref.mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
     got = np.array(Image.open(dst / "003.png"))
     assert np.abs(got.astype(int) - ref_u8.astype(int)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_evaluate_driver_on_a_tiny_testset(tmp_path, device):
+    """vfi_amd.evaluation.evaluate.eval (reference src/evaluation/evaluate.py:219-278): models built once, dataset loop,
+    device scoring, .npy cache, round-robin sharding of the test sets over ranks."""
+    from PIL import Image
+    from oracle import pipeline_cpu, synth
+    from vfi_amd.evaluation import evaluate as evl
+    root = tmp_path / "Testset"
+    frames = {}
+    for name, seed in (("ClipA", 3), ("ClipB", 4)):
+        (root / name).mkdir(parents=True)
+        for i in range(5):
+            f = synth.translating_pair(seed, 72, 104, shift=(1.5 * i, -1.0 * i))[2]
+            u8 = (f.transpose(1, 2, 0) * 255 + 0.5).astype(np.uint8)
+            Image.fromarray(u8).save(root / name / f"{i:03d}.png")
+            frames[(name, i)] = u8
+    w = pipeline_cpu.seeded_weights(0)
+    torch.save(w["fusionnet"], tmp_path / "fusion_net.pt")
+    torch.save(w["phasenet"], tmp_path / "phase_net.pt")
+    torch.save({"epoch": 0, "state_dict": w["adacof"]}, tmp_path / "ckpt.pth")
+    argv = ["--fusion", "--phase", "--adacof", "--baseline", "--base_dir", str(tmp_path / "Eval"), "--test_sets", "ClipA", "ClipB",
+            "--testset_root", str(root), "--dim", "64", "--max_num", "10", "--adacof_checkpoint", str(tmp_path / "ckpt.pth"),
+            "--adacof_config", "", "--phasenet_checkpoint", str(tmp_path / "phase_net.pt"),
+            "--fusion_checkpoint", str(tmp_path / "fusion_net.pt")]
+    args = evl.parser.parse_args(argv)
+    res = evl.eval(args, rank=1, world=2)                      # rank 1 of 2 owns ClipB only
+    assert list(res) == ["ClipB"] and not (tmp_path / "Eval" / "result_ClipA.npy").exists()
+    res = evl.eval(evl.parser.parse_args(argv), rank=0, world=1)
+    assert list(res) == ["ClipA", "ClipB"]
+    for name in ("ClipA", "ClipB"):
+        r = res[name]
+        assert r.shape == (3, 4, 7)                            # 3 triplets x (adacof, phase, fusion, baseline) x 7 measures
+        assert np.isnan(r[:, :, 1]).all() and np.isfinite(np.delete(r, 1, axis=2)).all()
+        for kind in ("fusion", "phasenet", "adacof", "baseline"):
+            assert sorted(os.listdir(tmp_path / "Eval" / "interpolated" / name / kind)) == ["0001.png", "0002.png", "0003.png"]
+        # PSNR / SSD columns re-derived on the host from the written PNGs (fusion = method index 2)
+        for i in range(3):
+            pred = np.array(Image.open(tmp_path / "Eval" / "interpolated" / name / "fusion" / f"{i + 1:04d}.png")).astype(np.float64) / 255
+            tgt = frames[(name, i)].astype(np.float64) / 255          # the reference's target index (evaluate.py:151,158)
+            crop = lambda a: a[(72 // 2 - 32):(72 // 2 + 32), (104 // 2 - 32):(104 // 2 + 32)]
+            d = crop(pred) - crop(tgt)
+            assert abs(r[i, 2, 2] - 10 * np.log10(1.0 / ((d ** 2).mean() + 1e-8))) <= 1e-3
+            assert abs(r[i, 2, 3] - np.sqrt((d ** 2).sum())) <= 1e-3
+    # --middle_frame_target scores against frame i+1 (the true middle frame) instead
+    args_m = evl.parser.parse_args(argv + ["--middle_frame_target", "--test_sets", "ClipA"])
+    mid = np.array(evl.evaluate_dataset(args_m, "ClipA"))
+    assert mid.shape == (3, 4, 7) and not np.allclose(mid[:, 2, 2], res["ClipA"][:, 2, 2])
+    pred = np.array(Image.open(tmp_path / "Eval" / "interpolated" / "ClipA" / "fusion" / "0001.png")).astype(np.float64) / 255
+    d = (pred - frames[("ClipA", 1)].astype(np.float64) / 255)[4:68, 20:84]
+    assert abs(mid[0, 2, 2] - 10 * np.log10(1.0 / ((d ** 2).mean() + 1e-8))) <= 1e-3
+    # second pass: everything is cached (PNGs skipped, arrays loaded)
+    stamp = os.path.getmtime(tmp_path / "Eval" / "result_ClipA.npy")
+    res2 = evl.eval(evl.parser.parse_args(argv), rank=0, world=1)
+    assert os.path.getmtime(tmp_path / "Eval" / "result_ClipA.npy") == stamp and np.array_equal(res2["ClipA"], res["ClipA"], equal_nan=True)

@@ -1,6 +1,7 @@
 """End-to-end parity of the fused per-frame path (product, on the MI355X) against the oracle pipeline
 (CPU) on seeded synthetic triplets, with the tolerances of BASELINE.md section 3."""
 import math
+import os
 import types
 
 import numpy as np
@@ -44,7 +45,7 @@ def test_fused_frame_matches_oracle(h, w, device):
     for k in ("ada_pred", "phase_pred", "base", "baseline", "final"):
         assert report[k] >= 60.0, (k, report)
     for k in ("flow_var_map", "phase_uncertainty", "ada_uncertainty"):
-        assert report[k] >= 50.0, (k, report)
+        assert report[k] >= 60.0, (k, report)
     # |PSNR(HIP, GT) - PSNR(CPU, GT)| <= 0.01 dB on the analytic middle frame
     assert abs(_psnr(got["final"].cpu()[0], f1_true) - _psnr(ref["final"][0], f1_true)) <= 0.01
 
@@ -91,6 +92,7 @@ def test_frame_is_capturable_into_a_hip_graph(device):
     a0, _, a2 = (torch.from_numpy(x).to(device) for x in synth.translating_pair(5, 64, 96))
     b0, _, b2 = (torch.from_numpy(x).to(device) for x in synth.translating_pair(6, 64, 96))
     want_a = run(a0, a2)["final"].clone()          # also warms up plans / packed weights
+    want_b = run(b0, b2)["final"].clone()          # both eager references BEFORE the capture (round-1 order restored)
     torch.cuda.synchronize()
     s = torch.cuda.Stream(device=device)
     f0, f2 = torch.empty_like(a0), torch.empty_like(a2)
@@ -108,9 +110,155 @@ def test_frame_is_capturable_into_a_hip_graph(device):
         s.synchronize()
         got_b = out.clone()
     torch.cuda.synchronize()
-    # the eager reference for the second input pair is taken AFTER the replay: nothing of it can have been around
-    # while the graph was captured or replayed
-    want_b = run(b0, b2)["final"]
-    torch.cuda.synchronize()
     assert torch.equal(got_b, want_b)
     assert not torch.equal(got_b, want_a)
+    # ... and an eager run after the replays still gives the same bits
+    assert torch.equal(run(b0, b2)["final"], want_b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1..3] at 1280x720 against the CPU oracle (the oracle needs ~30 s per fused frame at this size)
+# ---------------------------------------------------------------------------------------------------------------------
+H720, W720 = 720, 1280
+
+
+@pytest.fixture(scope="module")
+def pair_720():
+    return tuple(torch.from_numpy(x) for x in synth.translating_pair(11, H720, W720))
+
+
+def test_phasenet_branch_720p_matches_oracle(pair_720, device):
+    """configs[1]: steerable-pyramid decompose -> PhaseNet -> reconstruct at 1280x720 (6 Lab channel-images in, 3 out;
+    reference src/fusion_net/interpolate_twoframe.py:168-188) -- HIP pyramid kernels + PhaseNet vs the oracle."""
+    import numpy as np
+    from oracle import color_cpu, layout_cpu, nets_cpu, pyramid_cpu
+    from vfi_amd import ops
+    from vfi_amd.phase_net.phase_net import PhaseNet
+    from vfi_amd.train.pyramid import Pyramid
+    from vfi_amd.values import DecompValues
+    f0, _, f2 = pair_720
+    sd = pipeline_cpu.seeded_weights(0)["phasenet"]
+    height = layout_cpu.calc_pyr_height(H720, W720)
+    assert height == 15
+    lab = torch.cat((color_cpu.rgb2lab_single(f0), color_cpu.rgb2lab_single(f2)), 0).float()
+    opyr = pyramid_cpu.Pyramid(height, 4, np.sqrt(2))
+    vin = layout_cpu.get_concat_layers_inf(layout_cpu.separate_vals(opyr.filter(lab), 2))
+    normed, state = nets_cpu.phasenet_normalize(vin)
+    with torch.no_grad():
+        ref = opyr.inv_filter(nets_cpu.phasenet_forward(sd, normed, state, height))
+    pyr = Pyramid(height, 4, np.sqrt(2), device)
+    pyr.set_full_size(H720, W720)
+    net = PhaseNet(pyr, device)
+    net.load_state_dict(sd)
+    net.eval()
+    vals, bufs = pyr.filter(lab.to(device), concat_frames=2, phase_scale=1.0 / math.pi)
+    pred = net(net.normalize_vals(vals, concat=bufs))
+    got = pyr.inv_filter(DecompValues(0, pred.phase, pred.amplitude, pred.low_level)).cpu()
+    psnr = _psnr(got, ref)
+    print("configs[1] PhaseNet branch 720p vs oracle:", psnr, "dB")
+    assert psnr >= 60.0, psnr
+
+
+def test_adacof_720p_matches_oracle(pair_720, device):
+    """configs[2]: one AdaCoFNet forward (U-Net + fused sampling + occlusion blend + flow-variance mask) at 1280x720:
+    the 1080p-class routing of the Winograd kernel (run length, split-K cost model) against the oracle."""
+    from oracle import nets_cpu
+    f0, _, f2 = pair_720
+    sd = pipeline_cpu.seeded_weights(0)["adacof"]
+    with torch.no_grad():
+        _, t2_ref, frame_ref, mask_ref = nets_cpu.adacofnet_forward(sd, f0.unsqueeze(0), f2.unsqueeze(0))
+    args = types.SimpleNamespace(model="vfi_amd.fusion_net.fusion_adacofnet", kernel_size=5, dilation=1, gpu_id=0)
+    adacof = Model(args)
+    adacof.load(sd)
+    adacof.eval()
+    _, t2, frame, mask = adacof(f0.unsqueeze(0).to(device), f2.unsqueeze(0).to(device))
+    rep = {"frame1": _psnr(frame.cpu(), frame_ref), "t2": _psnr(t2.cpu(), t2_ref), "mask": _psnr(mask.cpu(), mask_ref)}
+    print("configs[2] AdaCoF 720p vs oracle:", rep)
+    assert min(rep.values()) >= 60.0, rep
+
+
+def test_fused_frame_720p_matches_oracle(pair_720, device):
+    """configs[3] (the full fused frame) at 1280x720, every stage output against the oracle pipeline."""
+    f0, f1_true, f2 = pair_720
+    weights = pipeline_cpu.seeded_weights(0)
+    ref = pipeline_cpu.interp(f0, f2, weights, output_baseline=True)
+    run = _models(device, weights)
+    got = run(f0.to(device), f2.to(device), output_baseline=True)
+    torch.cuda.synchronize()
+    report = {k: _psnr(got[k].cpu(), ref[k]) for k in ref}
+    print("configs[3] fused frame 720p vs oracle:", report)
+    for k, v in report.items():
+        assert v >= 60.0, (k, report)
+    assert abs(_psnr(got["final"].cpu()[0], f1_true) - _psnr(ref["final"][0], f1_true)) <= 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# frames in flight (bench.py / interpolate_video): same bits as sequential execution
+# ---------------------------------------------------------------------------------------------------------------------
+def test_two_frames_in_flight_equal_sequential_1080p(device):
+    """N frames (a) one after another on one stream with one interpolator and (b) two in flight on two streams with two
+    interpolators sharing the weights, exactly as bench.py's timed loop does -- at 1920x1080, bit for bit."""
+    h, w = 1080, 1920
+    weights = pipeline_cpu.seeded_weights(4)
+    args = types.SimpleNamespace(model="vfi_amd.fusion_net.fusion_adacofnet", kernel_size=5, dilation=1, gpu_id=0)
+    adacof = Model(args); adacof.load(weights["adacof"]); adacof.eval()
+    fusion = FusionNet().to(device); fusion.load_state_dict(weights["fusionnet"]); fusion.eval()
+    g = torch.Generator().manual_seed(5)
+    pairs = [(torch.rand((3, h, w), generator=g).to(device), torch.rand((3, h, w), generator=g).to(device)) for _ in range(2)]
+    n = 6
+    seq_runner = FusionInterpolator(adacof, fusion, weights["phasenet"], device)
+    seq = [seq_runner(*pairs[i % 2], output_baseline=True)["final"].clone() for i in range(n)]
+    torch.cuda.synchronize()
+    runners = [FusionInterpolator(adacof, fusion, weights["phasenet"], device) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    outs = []
+    for i in range(n):                      # no synchronisation inside the loop: frames i and i+1 overlap
+        with torch.cuda.stream(streams[i % 2]):
+            outs.append(runners[i % 2](*pairs[i % 2], output_baseline=True)["final"])
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(outs[i], seq[i]), i
+    assert torch.equal(seq[0], seq[2]) and not torch.equal(seq[0], seq[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the file entry point interp(args) (reference src/fusion_net/interpolate_twoframe.py:82-119,280-334)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_interp_png_entry_point_with_center_crop(tmp_path, device):
+    import numpy as np
+    from PIL import Image
+    from vfi_amd.fusion_net import interpolate_twoframe as it
+    weights = pipeline_cpu.seeded_weights(5)
+    dim, hh, ww = 96, 120, 136
+    f0, _, f2 = synth.translating_pair(9, hh, ww)
+    u8 = lambda f: (f.transpose(1, 2, 0) * 255 + 0.5).astype(np.uint8)
+    a, b = u8(f0), u8(f2)
+    Image.fromarray(a).save(tmp_path / "a.png"); Image.fromarray(b).save(tmp_path / "b.png")
+    torch.save(weights["fusionnet"], tmp_path / "fusion_net.pt")
+    torch.save(weights["phasenet"], tmp_path / "phase_net.pt")
+    torch.save({"epoch": 0, "state_dict": weights["adacof"]}, tmp_path / "ckpt.pth")
+    out = {k: str(tmp_path / f"{k}.png") for k in ("final", "phase", "adacof", "baseline")}
+    args = types.SimpleNamespace(
+        gpu_id=0, adacof_model="vfi_amd.fusion_net.fusion_adacofnet", adacof_kernel_size=5, adacof_dilation=1,
+        adacof_checkpoint=str(tmp_path / "ckpt.pth"), adacof_config=None, checkpoint=str(tmp_path / "fusion_net.pt"),
+        phase_net_checkpoint=str(tmp_path / "phase_net.pt"), first_frame=str(tmp_path / "a.png"),
+        second_frame=str(tmp_path / "b.png"), output_frame=out["final"], output_phase=True, output_frame_phase=out["phase"],
+        output_adacof=True, output_frame_adacof=out["adacof"], output_baseline=True, output_frame_baseline=out["baseline"],
+        dim=dim, high_level=False, model=1, mode="alpha")
+    it.interp(args)
+    # oracle on the same centre crop (interpolate_twoframe.py:75-79,109-113), quantised like save_image
+    crop = lambda img: it.crop_center(img, dim, dim)
+    t = lambda img: torch.from_numpy(crop(img).astype(np.float32) / 255).permute(2, 0, 1).contiguous()
+    ref = pipeline_cpu.interp(t(a), t(b), weights, output_baseline=True)
+    quant = lambda x: x[0].mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    for key, name in (("final", "final"), ("phase", "phase_pred"), ("adacof", "ada_pred"), ("baseline", "baseline")):
+        got = np.array(Image.open(out[key]))
+        want = quant(ref[name])
+        assert got.shape == (dim, dim, 3), key
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d == 0).mean() >= 0.99, (key, d.max(), (d == 0).mean())
+    # second call with the same checkpoints reuses the cached interpolator (no per-call rebuild of plans / packs)
+    n_cached = len(it._INTERPOLATORS)
+    os.remove(out["final"])
+    it.interp(args)
+    assert len(it._INTERPOLATORS) == n_cached and os.path.exists(out["final"])
