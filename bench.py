@@ -11,6 +11,10 @@ src/fusion_net/interpolate_twoframe.py:148-330 with output_baseline, as src/eval
 on synthetic frame pairs already resident in HBM.  Frames of a clip shard across ranks with no data-path
 collective (weak scaling: fixed work per GPU); weights are broadcast once from rank 0 over RCCL.
 Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` without a torchrun environment spawns its N ranks itself (a child
+`python -m torch.distributed.run ... bench.py`, started before this process has made any GPU call) and exits with
+the child's code.
 """
 import argparse
 import json
@@ -71,22 +75,74 @@ def build_runner(device, n_streams=1, seed=0):
     return [FusionInterpolator(adacof, fusion, state, device) for _ in range(n_streams)], n
 
 
-def cpu_baseline(sample_hw=(544, 960), full_hw=(1080, 1920), threads=16):
-    """The oracle pipeline (CPU restatement of the same path) on a bounded sample, scaled by pixel count."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(hw=(1080, 1920), runs=3, warmup=1, threads=None):
+    """BASELINE.md section 3 protocol: the oracle pipeline (CPU restatement of the same path, oracle/pipeline_cpu.py) on
+    the SAME workload (one fused frame with output_baseline at the benchmark size), `warmup` untimed + `runs` timed
+    runs on all host cores, frames/s = 1 / median whole-frame time."""
     from oracle import pipeline_cpu, synth
-    threads = max(1, min(threads, os.cpu_count() or 1))
+    threads = max(1, threads or os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    h, w = sample_hw
+    h, w = hw
     f0, _, f2 = (torch.from_numpy(x) for x in synth.translating_pair(0, h, w))
     weights = pipeline_cpu.seeded_weights(0)
-    stages = {}
-    t0 = time.perf_counter()
-    pipeline_cpu.interp(f0, f2, weights, output_baseline=True, timings=stages)
-    t = time.perf_counter() - t0
-    scale = (full_hw[0] * full_hw[1]) / (h * w)
-    return {"value": 1.0 / (t * scale), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"one fused frame at {w}x{h} ({t:.1f} s on {threads} threads), scaled x{scale:.2f} by pixel count to 1920x1080",
-            "stage_seconds": {k: round(v, 3) for k, v in stages.items()}}
+    times, stages = [], []
+    for i in range(warmup + runs):
+        st = {}
+        t0 = time.perf_counter()
+        pipeline_cpu.interp(f0, f2, weights, output_baseline=True, timings=st)
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+            stages.append(st)
+    med = float(np.median(times))
+    st = stages[int(np.argsort(times)[len(times) // 2])]
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{warmup} warm-up + {runs} timed fused frames at {w}x{h} (the benchmark workload itself), median "
+                      f"{med:.1f} s of {[round(t, 1) for t in times]} on {threads} threads",
+            "stage_seconds": {k: round(v, 3) for k, v in st.items()}}
+
+
+def spawn_ranks(n):
+    """Parent of a bare `python bench.py --gpus N`: starts the N ranks through torch.distributed.run and relays their
+    exit code.  Nothing in this process has touched HIP (device_count() does not initialise the runtime)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit(f"bench.py: --gpus {n} but this node shows {have} GPU(s)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    runs of this benchmark, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes the file)."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    try:
+        with open(path) as f:
+            rows = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    row = rows.get(kernel)
+    if not row:
+        return None, None
+    return row["bytes_per_launch"], {"source": "profiles/r02_traffic.json", **{k: v for k, v in row.items() if k != "bytes_per_launch"}}
 
 
 def main():
@@ -101,8 +157,11 @@ def main():
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture each in-flight frame's ~700 launches into a hipGraph (torch.cuda.CUDAGraph) and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-runs", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                               # never returns
 
     from vfi_amd import _lib, shard
     rank, local_rank, world = shard.init_distributed()
@@ -178,10 +237,12 @@ def main():
                            "sharding": f"frame pairs over {world} rank(s), no data-path collective",
                            "frames_in_flight_per_gpu": args.streams, "hip_graph": bool(args.graph)}}
         if not args.no_profile:
-            # Per-kernel algorithmic work / measured duration (HIP events on the launch stream of each call).
-            #  * "roofline": measured in the SAME regime as the timed region (one frame per stream, S frames in
-            #    flight), so its average launch duration is the one rocprofv3 --stats reports for this command;
-            #  * "roofline_isolated": one frame alone on the device (kernel quality without sharing the chip).
+            # Per-kernel algorithmic work / measured launch duration: HIP events on the launch stream around every library
+            # call, over ONE frame running ALONE on the device on one stream after the timed region.  (With two frames in
+            # flight the events of two streams overlap in time and would double-count, and a kernel's duration depends on
+            # what the other stream happens to run beside it; `rocprofv3 --kernel-trace --stats -- python3 bench.py
+            # --streams 1` reproduces these averages, profiles/.)  Sum over a frame of avg_launch_ms x launches stays
+            # below the single-stream frame time by construction.
             prof_step = eager_step if args.graph else step
 
             def profile(n_frames):
@@ -193,30 +254,31 @@ def main():
                 _lib.PROFILE = None
                 return agg
 
-            def roof(agg):
-                convs = {k: v for k, v in agg.items() if v["kind"] == "flop"}
-                dom = max(convs, key=lambda k: convs[k]["seconds"])
-                d = convs[dom]
-                tf = d["work"] / d["seconds"] / 1e12
-                r = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                     "launches": d["calls"], "avg_launch_ms": d["seconds"] / d["calls"] * 1e3,
-                     "share_of_kernel_time": d["seconds"] / sum(v["seconds"] for v in agg.values())}
-                if "winograd" in dom:
-                    # `achieved` counts the Winograd algorithm's own multiply-adds (16 per 2x2 outputs and channel pair:
-                    # what the matrix cores execute); the same convolutions done directly are 36
-                    r["flops_counted"] = "Winograd F(2x2,3x3): 2*N*Cin*Cout*16*(H*W/4) per launch"
-                    r["direct_conv_equivalent_tflops"] = tf * 2.25
-                return r
-
-            agg = profile(len(runners))
-            line["roofline"] = roof(agg)
-            if len(runners) > 1:
-                saved, runners[:] = list(runners), runners[:1]
-                agg = profile(1)
-                runners[:] = saved
-                line["roofline_isolated"] = roof(agg)
-            dom = line["roofline"]["kernel"]
+            saved, runners[:] = list(runners), runners[:1]
+            profile(1)                                        # (first profiled frame also creates the event objects)
+            t0 = time.perf_counter()
+            agg = profile(1)
+            alone_ms = (time.perf_counter() - t0) * 1e3
+            runners[:] = saved
+            convs = {k: v for k, v in agg.items() if v["kind"] == "flop"}
+            dom = max(convs, key=lambda k: convs[k]["seconds"])
+            d = convs[dom]
+            tf = d["work"] / d["seconds"] / 1e12
+            traffic, traffic_note = measured_traffic(dom)
+            line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches_per_frame": d["calls"],
+                                "avg_launch_ms": d["seconds"] / d["calls"] * 1e3, "kernel_ms_per_frame": d["seconds"] * 1e3,
+                                "frame_ms_alone_one_stream": alone_ms,
+                                "share_of_kernel_time": d["seconds"] / sum(v["seconds"] for v in agg.values()),
+                                "regime": "one frame alone on the device, one stream (HIP events on the launch stream)",
+                                "algorithmic_gflop_per_launch": d["work"] / d["calls"] / 1e9}
+            if traffic_note:
+                line["roofline"]["traffic_note"] = traffic_note
+            if "winograd" in dom:
+                # `achieved` counts the Winograd algorithm's own multiply-adds (16 per 2x2 outputs and channel pair: what
+                # the matrix cores execute); the same convolutions done directly are 36
+                line["roofline"]["flops_counted"] = "Winograd F(2x2,3x3): 2*N*Cin*Cout*16*(H*W/4) per launch"
+                line["roofline"]["direct_conv_equivalent_tflops"] = tf * 2.25
             line["roofline_other"] = []
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"]):
                 if k == dom or not v["kind"]:
@@ -228,7 +290,7 @@ def main():
                                                "calls": v["calls"], "ms_per_frame": v["seconds"] * 1e3})
             line["stage_ms_isolated"] = {k: round(v["seconds"] * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"])[:14]}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline((h, w), runs=args.cpu_baseline_runs)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -117,7 +117,7 @@ def test_evaluate_driver_on_a_tiny_testset(tmp_path, device):
             pred = np.array(Image.open(tmp_path / "Eval" / "interpolated" / name / "fusion" / f"{i + 1:04d}.png")).astype(np.float64) / 255
             tgt = frames[(name, i)].astype(np.float64) / 255          # the reference's target index (evaluate.py:151,158)
             crop = lambda a: a[(72 // 2 - 32):(72 // 2 + 32), (104 // 2 - 32):(104 // 2 + 32)]
-            d = crop(pred) - crop(tgt)
+            d = pred - crop(tgt)                                   # predictions are written at dim x dim already
             assert abs(r[i, 2, 2] - 10 * np.log10(1.0 / ((d ** 2).mean() + 1e-8))) <= 1e-3
             assert abs(r[i, 2, 3] - np.sqrt((d ** 2).sum())) <= 1e-3
     # --middle_frame_target scores against frame i+1 (the true middle frame) instead
@@ -125,7 +125,7 @@ def test_evaluate_driver_on_a_tiny_testset(tmp_path, device):
     mid = np.array(evl.evaluate_dataset(args_m, "ClipA"))
     assert mid.shape == (3, 4, 7) and not np.allclose(mid[:, 2, 2], res["ClipA"][:, 2, 2])
     pred = np.array(Image.open(tmp_path / "Eval" / "interpolated" / "ClipA" / "fusion" / "0001.png")).astype(np.float64) / 255
-    d = (pred - frames[("ClipA", 1)].astype(np.float64) / 255)[4:68, 20:84]
+    d = pred - (frames[("ClipA", 1)].astype(np.float64) / 255)[4:68, 20:84]
     assert abs(mid[0, 2, 2] - 10 * np.log10(1.0 / ((d ** 2).mean() + 1e-8))) <= 1e-3
     # second pass: everything is cached (PNGs skipped, arrays loaded)
     stamp = os.path.getmtime(tmp_path / "Eval" / "result_ClipA.npy")
