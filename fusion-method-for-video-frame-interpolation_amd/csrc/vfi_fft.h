@@ -1,0 +1,340 @@
+// Workgroup-cooperative complex FFT in LDS for gfx950 -- the transform engine of the steerable pyramid
+// (the arithmetic the reference gets from torch.fft inside the third-party `steerable.SCFpyr_PyTorch`, call sites
+// src/train/pyramid.py:37,44).  No FFT library is involved.
+//
+//   * `lines` independent transforms of length n live side by side in one LDS buffer (line l at buf + l*pitch);
+//     256 threads work on all of them together.  lines * m <= kMaxElems (m = the length actually transformed).
+//   * smooth lengths (factors 2, 3, 5) run a mixed-radix Stockham autosort FFT with radices {16, 8, 4, 2, 3, 5}:
+//     natural order in, natural order out.  One stage of radix R (p = product of the previous radices, T = m / R):
+//         butterfly i in [0, T):  k = i % p;  u[r] = x[i + r*T] * W_m^(r * k * m/(p*R));  v = DFT_R(u);
+//                                 y[(i/p)*p*R + k + r*p] = v[r]
+//     done IN PLACE: every thread gathers its butterflies into registers, the workgroup synchronises, the results are
+//     scattered back -- one LDS buffer, <= 35 complex values per thread.
+//   * any other length (the sqrt(2)-scaled pyramid levels: 1358 = 2*7*97, 764 = 4*191, 679, 382, 191, 43 ...) runs
+//     Bluestein's chirp-z form on a power-of-two length M >= 2n-1 through the same stages:
+//         X[k] = w[k] * sum_j (x[j] w[j]) * conj(w[k-j]),  w[j] = exp(-i pi j^2 / n)
+//     = w[k] * IFFT_M( FFT_M(x w, zero padded) * B ),  B = FFT_M(conj(w) wrapped) / M  (precomputed in double);
+//     the inverse transform uses the conjugate tables (w is even in j, so B is too).
+//   * twiddles come from per-length tables built in double precision (exp(-2 pi i k / m), k < m); a butterfly loads
+//     W^k, W^2k, W^4k, W^8k and forms the other powers with at most two further products.
+// Transforms are un-normalised in both directions (torch.fft's 1/n of the inverse is applied by the callers).
+//
+// Everything below is __host__ __device__ with the thread index passed in, so tests/fft_host_check.cpp can run the
+// very same index arithmetic on the CPU by looping over "threads" between the synchronisation points.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vfi {
+namespace fft {
+
+constexpr int kThreads = 256;
+constexpr int kMaxElems = 8192;      // complex values of all lines of one workgroup (64 KiB of LDS)
+constexpr int kMaxStages = 8;
+
+struct Plan1D {                      // plain data, passed to kernels by value
+    int n;                           // transform length
+    int m;                           // length run through the stages: n (smooth) or the Bluestein length M
+    int nstages, bluestein;
+    int radix[kMaxStages];
+    const float2 *tw;                // m entries  exp(-2 pi i k / m)
+    const float2 *chirp;             // n entries  exp(-i pi j^2 / n)            (Bluestein only)
+    const float2 *bfilt;             // m entries  FFT_M(conj(chirp) wrapped) / M (Bluestein only)
+};
+
+#define VFI_HD __host__ __device__ __forceinline__
+
+VFI_HD float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+VFI_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+VFI_HD float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+VFI_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// multiply by -i (forward transform) or +i (inverse)
+template <bool INV> VFI_HD float2 rot(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+// multiply by exp(-+ i pi/4) * sqrt(2)/... : W8^1 (forward: (1 - i)/sqrt2, inverse: (1 + i)/sqrt2)
+template <bool INV> VFI_HD float2 w8_1(float2 a) {
+    constexpr float h = 0.70710678118654752440f;
+    return INV ? make_float2(h * (a.x - a.y), h * (a.x + a.y)) : make_float2(h * (a.x + a.y), h * (a.y - a.x));
+}
+template <bool INV> VFI_HD float2 w8_3(float2 a) {   // W8^3 (forward: (-1 - i)/sqrt2, inverse: (-1 + i)/sqrt2)
+    constexpr float h = 0.70710678118654752440f;
+    return INV ? make_float2(-h * (a.x + a.y), h * (a.x - a.y)) : make_float2(h * (a.y - a.x), -h * (a.x + a.y));
+}
+
+template <int R, bool INV> struct Dft;
+template <bool INV> struct Dft<2, INV> {
+    static VFI_HD void run(float2 *v) {
+        const float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b); v[1] = csub(a, b);
+    }
+};
+template <bool INV> struct Dft<3, INV> {
+    static VFI_HD void run(float2 *v) {
+        const float2 a = v[0], s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+        const float2 m = make_float2(a.x - 0.5f * s.x, a.y - 0.5f * s.y);
+        const float2 q = rot<INV>(make_float2(0.86602540378443864676f * d.x, 0.86602540378443864676f * d.y));
+        v[0] = cadd(a, s); v[1] = cadd(m, q); v[2] = csub(m, q);
+    }
+};
+template <bool INV> struct Dft<4, INV> {
+    static VFI_HD void run(float2 *v) {
+        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = rot<INV>(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+    }
+};
+template <bool INV> struct Dft<5, INV> {
+    static VFI_HD void run(float2 *v) {
+        constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;   // cos(2pi/5), cos(4pi/5)
+        constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;    // sin(2pi/5), sin(4pi/5)
+        const float2 a = v[0], t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+        const float2 m1 = make_float2(a.x + c1 * t1.x + c2 * t2.x, a.y + c1 * t1.y + c2 * t2.y);
+        const float2 m2 = make_float2(a.x + c2 * t1.x + c1 * t2.x, a.y + c2 * t1.y + c1 * t2.y);
+        const float2 n1 = rot<INV>(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+        const float2 n2 = rot<INV>(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+        v[0] = make_float2(a.x + t1.x + t2.x, a.y + t1.y + t2.y);
+        v[1] = cadd(m1, n1); v[4] = csub(m1, n1);
+        v[2] = cadd(m2, n2); v[3] = csub(m2, n2);
+    }
+};
+template <bool INV> struct Dft<8, INV> {
+    static VFI_HD void run(float2 *v) {
+        float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+        Dft<4, INV>::run(e);
+        Dft<4, INV>::run(o);
+        o[1] = w8_1<INV>(o[1]); o[2] = rot<INV>(o[2]); o[3] = w8_3<INV>(o[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+    }
+};
+template <bool INV> struct Dft<16, INV> {
+    // k = q + 4s, input index c + 4r:  X[q+4s] = sum_c W4^(cs) * W16^(cq) * (sum_r x[c+4r] W4^(rq))
+    static VFI_HD void run(float2 *v) {
+        float2 t[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float2 col[4] = {v[c], v[c + 4], v[c + 8], v[c + 12]};
+            Dft<4, INV>::run(col);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[c][q] = col[q];
+        }
+        // W16^e, e = c*q: cos/sin(2 pi e / 16)
+        constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+        auto tw = [](float2 a, float cr, float si) {   // a * (cr - i si) forward, a * (cr + i si) inverse
+            return INV ? make_float2(a.x * cr - a.y * si, a.x * si + a.y * cr) : make_float2(a.x * cr + a.y * si, a.y * cr - a.x * si);
+        };
+        t[1][1] = tw(t[1][1], c1, s1);            // e = 1
+        t[1][2] = tw(t[1][2], h, h);              // e = 2
+        t[1][3] = tw(t[1][3], s1, c1);            // e = 3
+        t[2][1] = tw(t[2][1], h, h);              // e = 2
+        t[2][2] = rot<INV>(t[2][2]);              // e = 4
+        t[2][3] = tw(t[2][3], -h, h);             // e = 6
+        t[3][1] = tw(t[3][1], s1, c1);            // e = 3
+        t[3][2] = tw(t[3][2], -h, h);             // e = 6
+        t[3][3] = tw(t[3][3], -c1, -s1);          // e = 9
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float2 row[4] = {t[0][q], t[1][q], t[2][q], t[3][q]};
+            Dft<4, INV>::run(row);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[q + 4 * s] = row[s];
+        }
+    }
+};
+
+// exact floor(t / d) for 0 <= t < 2^15, 1 <= d < 2^15 through a float reciprocal (the distance of (t + 0.5) / d from
+// an integer is >= 0.5 / d, far above the rounding error)
+VFI_HD int fast_div(int t, float inv_d) { return (int)(((float)t + 0.5f) * inv_d); }
+
+template <int R> struct StageRegs {
+    static constexpr int QB = ((kMaxElems + R - 1) / R + kThreads - 1) / kThreads;   // butterflies per thread
+    float2 v[QB][R];
+};
+
+// ---- one Stockham stage, in two halves around a workgroup synchronisation -----------------------------------------
+template <int R, bool INV>
+VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines, int pitch, int m, int p,
+                         const float2 *__restrict__ tw) {
+    const int T = m / R, total = lines * T, twstep = m / (p * R);
+    const float inv_T = 1.0f / (float)T, inv_p = 1.0f / (float)p;
+#pragma unroll
+    for (int q = 0; q < StageRegs<R>::QB; ++q) {
+        const int t = tid + kThreads * q;
+        if (t < total) {
+            const int line = fast_div(t, inv_T), i = t - line * T, k = i - fast_div(i, inv_p) * p;
+            const float2 *x = buf + line * pitch + i;
+#pragma unroll
+            for (int r = 0; r < R; ++r) s.v[q][r] = x[r * T];
+            if (p > 1) {                       // (first stage: every twiddle is 1)
+                const int e = k * twstep;      // r * e < m for r < R
+                float2 w[R];
+                w[1] = tw[e];
+                if (R > 2) w[2] = tw[2 * e];
+                if (R > 4) w[4] = tw[4 * e];
+                if (R > 8) w[8] = tw[8 * e];
+                if (INV) {
+                    w[1] = cconj(w[1]);
+                    if (R > 2) w[2] = cconj(w[2]);
+                    if (R > 4) w[4] = cconj(w[4]);
+                    if (R > 8) w[8] = cconj(w[8]);
+                }
+                if (R > 3) w[3] = cmul(w[1], w[2]);
+                if (R > 5) { w[5] = cmul(w[4], w[1]); }
+                if (R > 6) { w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]); }
+                if (R > 9) {
+                    w[9] = cmul(w[8], w[1]); w[10] = cmul(w[8], w[2]); w[11] = cmul(w[8], w[3]); w[12] = cmul(w[8], w[4]);
+                    w[13] = cmul(w[8], w[5]); w[14] = cmul(w[8], w[6]); w[15] = cmul(w[8], w[7]);
+                }
+#pragma unroll
+                for (int r = 1; r < R; ++r) s.v[q][r] = cmul(s.v[q][r], w[r]);
+            }
+            Dft<R, INV>::run(s.v[q]);
+        }
+    }
+}
+
+template <int R>
+VFI_HD void stage_scatter(const StageRegs<R> &s, int tid, float2 *buf, int lines, int pitch, int m, int p) {
+    const int T = m / R, total = lines * T;
+    const float inv_T = 1.0f / (float)T, inv_p = 1.0f / (float)p;
+#pragma unroll
+    for (int q = 0; q < StageRegs<R>::QB; ++q) {
+        const int t = tid + kThreads * q;
+        if (t < total) {
+            const int line = fast_div(t, inv_T), i = t - line * T, g = fast_div(i, inv_p), k = i - g * p;
+            float2 *y = buf + line * pitch + g * p * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) y[r * p] = s.v[q][r];
+        }
+    }
+}
+
+// ---- element-wise steps of Bluestein's form ------------------------------------------------------------------------
+// buf[l][j] *= chirp[j] (conjugated for the inverse) for j < n, buf[l][j] = 0 for n <= j < m
+template <bool INV>
+VFI_HD void bluestein_pre(int tid, float2 *buf, int lines, int pitch, const Plan1D &pl) {
+    for (int l = 0; l < lines; ++l)
+        for (int j = tid; j < pl.m; j += kThreads) {
+            float2 z = make_float2(0.0f, 0.0f);
+            if (j < pl.n) {
+                float2 c = pl.chirp[j];
+                if (INV) c = cconj(c);
+                z = cmul(buf[l * pitch + j], c);
+            }
+            buf[l * pitch + j] = z;
+        }
+}
+template <bool INV>
+VFI_HD void bluestein_mid(int tid, float2 *buf, int lines, int pitch, const Plan1D &pl) {
+    for (int j = tid; j < pl.m; j += kThreads) {
+        float2 b = pl.bfilt[j];
+        if (INV) b = cconj(b);
+        for (int l = 0; l < lines; ++l) buf[l * pitch + j] = cmul(buf[l * pitch + j], b);
+    }
+}
+template <bool INV>
+VFI_HD void bluestein_post(int tid, float2 *buf, int lines, int pitch, const Plan1D &pl) {
+    for (int j = tid; j < pl.n; j += kThreads) {
+        float2 c = pl.chirp[j];
+        if (INV) c = cconj(c);
+        for (int l = 0; l < lines; ++l) buf[l * pitch + j] = cmul(buf[l * pitch + j], c);
+    }
+}
+
+// ---- device entry: all 256 threads of the workgroup call it; buf must be filled and synchronised ----------------------
+template <int R, bool INV>
+__device__ __forceinline__ void stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *__restrict__ tw) {
+    StageRegs<R> s;
+    stage_gather<R, INV>(s, threadIdx.x, buf, lines, pitch, m, p, tw);
+    __syncthreads();
+    stage_scatter<R>(s, threadIdx.x, buf, lines, pitch, m, p);
+    __syncthreads();
+}
+template <bool INV>
+__device__ __forceinline__ void stages(float2 *buf, int lines, int pitch, const Plan1D &pl) {
+    int p = 1;
+    for (int s = 0; s < pl.nstages; ++s) {
+        switch (pl.radix[s]) {
+            case 16: stage<16, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            case 8: stage<8, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            case 4: stage<4, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            case 2: stage<2, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            case 3: stage<3, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            default: stage<5, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+        }
+        p *= pl.radix[s];
+    }
+}
+// `lines` transforms of length pl.n at buf[l * pitch + j] (pitch >= pl.m), results in place at [0, pl.n) of each line.
+template <bool INV>
+__device__ __forceinline__ void fft_lines(float2 *buf, int lines, int pitch, const Plan1D &pl) {
+    if (!pl.bluestein) {
+        stages<INV>(buf, lines, pitch, pl);
+        return;
+    }
+    bluestein_pre<INV>(threadIdx.x, buf, lines, pitch, pl);
+    __syncthreads();
+    stages<false>(buf, lines, pitch, pl);
+    bluestein_mid<INV>(threadIdx.x, buf, lines, pitch, pl);
+    __syncthreads();
+    stages<true>(buf, lines, pitch, pl);
+    bluestein_post<INV>(threadIdx.x, buf, lines, pitch, pl);
+    __syncthreads();
+}
+
+// ---- host-side planning ----------------------------------------------------------------------------------------------
+// radices for a smooth length (16s, then 8, 4, 2, then 3s and 5s); false when n has another prime factor
+inline bool factor_smooth(int n, int *radix, int *nstages) {
+    int m = n, ns = 0;
+    for (int r : {16, 8, 4, 2, 3, 5})
+        while (m % r == 0) {
+            if (ns >= kMaxStages) return false;
+            radix[ns++] = r;
+            m /= r;
+        }
+    *nstages = ns;
+    return m == 1 && n >= 2;
+}
+inline int bluestein_length(int n) {
+    int M = 1;
+    while (M < 2 * n - 1) M *= 2;
+    return M;
+}
+// how many lines of this plan fit into one workgroup's buffer
+inline int max_lines(const Plan1D &pl) { return kMaxElems / pl.m; }
+
+}  // namespace fft
+}  // namespace vfi
+
+// ---- generic batched passes (vfi_fft.hip) ---------------------------------------------------------------------------
+namespace vfi {
+namespace fft {
+
+// how a row pass reads / writes its rows
+enum RowLoad { kLoadComplex = 0, kLoadReal = 1, kLoadHalf = 2 };      // Half: first n/2+1 entries given, rest by Hermitian symmetry
+enum RowStore { kStoreComplex = 0, kStoreReal = 1, kStoreHalf = 2 };  // Half: only the first n/2+1 entries are written
+
+struct RowArgs {
+    Plan1D pl;
+    const void *src;
+    void *dst;
+    long long rows;            // rows of all planes together (they are `pl.n` long)
+    int src_pitch, dst_pitch;  // elements between consecutive rows
+    int lines;                 // rows per workgroup
+    float scale;               // applied on store
+};
+struct ColArgs {
+    Plan1D pl;                 // pl.n = column length (rows of a plane)
+    float2 *data;              // [planes][pl.n][ld], transformed in place
+    int planes, cols, ld;      // cols <= ld columns are transformed
+    int tile;                  // columns per workgroup (power of two)
+    float scale;
+};
+
+// builds the tables of one length on the device (double precision on the host); every allocation is appended to `owned`
+int make_plan(int n, Plan1D *out, void (*own)(void *ctx, void *dev), void *ctx);
+
+int launch_rows(const RowArgs &a, RowLoad load, RowStore store, bool inverse, hipStream_t s);
+int launch_cols(const ColArgs &a, bool inverse, hipStream_t s);
+int rows_per_group(const Plan1D &pl, long long total_rows);
+int cols_per_group(const Plan1D &pl, int cols);
+
+}  // namespace fft
+}  // namespace vfi

@@ -1,0 +1,184 @@
+// Batched 1-D FFT passes over rows / column tiles of dense 2-D arrays, built on the LDS engine of vfi_fft.h: the
+// plain (un-fused) transforms of the steerable pyramid (R2C / C2R of the image and the high residual, the low
+// residual, vfi_pyr_apply_filter) and the building blocks the fused level kernels of vfi_pyramid.hip follow.
+//
+//   row pass    : a workgroup owns `lines` consecutive rows (of any planes: rows are one flat list); coalesced loads
+//                 straight into the LDS lines, transform, coalesced stores.  Real input / real output / Hermitian half
+//                 rows are load / store variants, so R2C and C2R cost no extra pass.
+//   column pass : a workgroup owns `tile` adjacent columns of one plane: rows of tile*8 bytes are read into LDS
+//                 transposed (line = column, odd line pitch: conflict-free), transformed, written back in place.
+// Roofline: HBM (each pass reads and writes the array once); the engine itself is LDS-bound.
+#include "vfi_common.h"
+#include "vfi_fft.h"
+
+#include <cmath>
+#include <complex>
+#include <vector>
+
+namespace vfi {
+namespace fft {
+namespace {
+
+using cd = std::complex<double>;
+constexpr double kPi = 3.14159265358979323846;
+
+void host_fft_pow2(std::vector<cd> &a) {       // in-place radix-2, forward, double precision (table building only)
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const cd w = std::polar(1.0, -2.0 * kPi * (double)k / (double)len);
+                const cd u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+template <int LOAD, int STORE, bool INV>
+__global__ __launch_bounds__(kThreads) void fft_rows_kernel(const RowArgs a) {
+    extern __shared__ float2 buf[];
+    const int n = a.pl.n, pitch = a.pl.m, tid = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * a.lines;
+    const int lines = (int)(a.rows - row0 < a.lines ? a.rows - row0 : a.lines);
+    const int total = lines * n;
+    const float inv_n = 1.0f / (float)n;
+    const int wh = n / 2 + 1;
+    for (int e = tid; e < total; e += kThreads) {
+        const int l = fast_div(e, inv_n), j = e - l * n;
+        float2 z;
+        if (LOAD == kLoadComplex) {
+            z = static_cast<const float2 *>(a.src)[(row0 + l) * a.src_pitch + j];
+        } else if (LOAD == kLoadReal) {
+            z = make_float2(static_cast<const float *>(a.src)[(row0 + l) * a.src_pitch + j], 0.0f);
+        } else {
+            const float2 *r = static_cast<const float2 *>(a.src) + (row0 + l) * a.src_pitch;
+            z = j < wh ? r[j] : cconj(r[n - j]);
+        }
+        buf[l * pitch + j] = z;
+    }
+    __syncthreads();
+    fft_lines<INV>(buf, lines, pitch, a.pl);
+    const int nout = STORE == kStoreHalf ? wh : n;
+    const float inv_o = 1.0f / (float)nout;
+    const int total_o = lines * nout;
+    for (int e = tid; e < total_o; e += kThreads) {
+        const int l = fast_div(e, inv_o), j = e - l * nout;
+        const float2 z = buf[l * pitch + j];
+        if (STORE == kStoreReal) static_cast<float *>(a.dst)[(row0 + l) * a.dst_pitch + j] = z.x * a.scale;
+        else static_cast<float2 *>(a.dst)[(row0 + l) * a.dst_pitch + j] = make_float2(z.x * a.scale, z.y * a.scale);
+    }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(kThreads) void fft_cols_kernel(const ColArgs a) {
+    extern __shared__ float2 buf[];
+    const int h = a.pl.n, pitch = a.pl.m | 1, tid = threadIdx.x, C = a.tile;
+    const int v0 = blockIdx.x * C;
+    const int lines = a.cols - v0 < C ? a.cols - v0 : C;
+    float2 *plane = a.data + (size_t)blockIdx.y * h * a.ld + v0;
+    const int shift = __ffs(C) - 1, total = h * C;
+    for (int e = tid; e < total; e += kThreads) {
+        const int u = e >> shift, c = e & (C - 1);
+        if (c < lines) buf[c * pitch + u] = plane[(size_t)u * a.ld + c];
+    }
+    __syncthreads();
+    fft_lines<INV>(buf, lines, pitch, a.pl);
+    for (int e = tid; e < total; e += kThreads) {
+        const int u = e >> shift, c = e & (C - 1);
+        if (c < lines) {
+            const float2 z = buf[c * pitch + u];
+            plane[(size_t)u * a.ld + c] = make_float2(z.x * a.scale, z.y * a.scale);
+        }
+    }
+}
+
+template <int LOAD, int STORE>
+void launch_rows_dir(const RowArgs &a, bool inverse, dim3 grid, size_t lds, hipStream_t s) {
+    if (inverse) hipLaunchKernelGGL((fft_rows_kernel<LOAD, STORE, true>), grid, dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL((fft_rows_kernel<LOAD, STORE, false>), grid, dim3(kThreads), lds, s, a);
+}
+
+}  // namespace
+
+int make_plan(int n, Plan1D *out, void (*own)(void *ctx, void *dev), void *ctx) {
+    Plan1D pl{};
+    pl.n = n;
+    pl.bluestein = factor_smooth(n, pl.radix, &pl.nstages) ? 0 : 1;
+    pl.m = pl.bluestein ? bluestein_length(n) : n;
+    if (pl.m > kMaxElems) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d needs %d LDS elements (max %d)", n, pl.m, kMaxElems);
+    if (pl.bluestein && !factor_smooth(pl.m, pl.radix, &pl.nstages)) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d", n);
+    auto upload = [&](const std::vector<cd> &v, const float2 **dev) -> int {
+        std::vector<float2> f(v.size());
+        for (size_t i = 0; i < v.size(); ++i) f[i] = make_float2((float)v[i].real(), (float)v[i].imag());
+        void *d = nullptr;
+        if (hipMalloc(&d, f.size() * sizeof(float2)) != hipSuccess) return vfi::fail(VFI_ERR_NOMEM, "FFT tables: device allocation");
+        own(ctx, d);
+        if (hipMemcpy(d, f.data(), f.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+            return vfi::fail(VFI_ERR_LAUNCH, "FFT tables: upload");
+        *dev = static_cast<const float2 *>(d);
+        return VFI_OK;
+    };
+    std::vector<cd> tw(pl.m);
+    for (int k = 0; k < pl.m; ++k) tw[k] = std::polar(1.0, -2.0 * kPi * (double)k / (double)pl.m);
+    int rc = upload(tw, &pl.tw);
+    if (rc) return rc;
+    if (pl.bluestein) {
+        std::vector<cd> w(n), b(pl.m, cd(0.0, 0.0));
+        for (int j = 0; j < n; ++j) w[j] = std::polar(1.0, -kPi * (double)(((long long)j * j) % (2LL * n)) / (double)n);
+        b[0] = std::conj(w[0]);
+        for (int j = 1; j < n; ++j) b[j] = b[pl.m - j] = std::conj(w[j]);
+        host_fft_pow2(b);
+        for (auto &v : b) v /= (double)pl.m;
+        if ((rc = upload(w, &pl.chirp)) || (rc = upload(b, &pl.bfilt))) return rc;
+    }
+    *out = pl;
+    return VFI_OK;
+}
+
+// rows per workgroup: as many as fit, but keep >= ~1024 workgroups in the launch when the array is large enough
+int rows_per_group(const Plan1D &pl, long long total_rows) {
+    long long l = max_lines(pl), want = (total_rows + 1023) / 1024;
+    if (want < 1) want = 1;
+    if (l > want) l = want;
+    // a thread should still hold a handful of butterflies: at least ~2048 elements per workgroup when rows are short
+    const long long min_l = (2048 + pl.m - 1) / pl.m;
+    if (l < min_l) l = min_l;
+    if (l > max_lines(pl)) l = max_lines(pl);
+    if (l > total_rows) l = total_rows;
+    return (int)(l < 1 ? 1 : l);
+}
+int cols_per_group(const Plan1D &pl, int cols) {
+    int c = 1;
+    while (c * 2 <= max_lines(pl) && c * 2 <= 32 && c < cols) c *= 2;
+    return c;
+}
+
+int launch_rows(const RowArgs &a, RowLoad load, RowStore store, bool inverse, hipStream_t s) {
+    const dim3 grid((unsigned)((a.rows + a.lines - 1) / a.lines));
+    const size_t lds = (size_t)a.lines * a.pl.m * sizeof(float2);
+    if (load == kLoadComplex && store == kStoreComplex) launch_rows_dir<kLoadComplex, kStoreComplex>(a, inverse, grid, lds, s);
+    else if (load == kLoadReal && store == kStoreComplex) launch_rows_dir<kLoadReal, kStoreComplex>(a, inverse, grid, lds, s);
+    else if (load == kLoadReal && store == kStoreHalf) launch_rows_dir<kLoadReal, kStoreHalf>(a, inverse, grid, lds, s);
+    else if (load == kLoadComplex && store == kStoreReal) launch_rows_dir<kLoadComplex, kStoreReal>(a, inverse, grid, lds, s);
+    else if (load == kLoadHalf && store == kStoreReal) launch_rows_dir<kLoadHalf, kStoreReal>(a, inverse, grid, lds, s);
+    else return vfi::fail(VFI_ERR_UNSUPPORTED, "fft row pass: load %d / store %d", (int)load, (int)store);
+    return vfi::check_launch("fft row pass");
+}
+
+int launch_cols(const ColArgs &a, bool inverse, hipStream_t s) {
+    const dim3 grid((unsigned)vfi::ceil_div(a.cols, a.tile), (unsigned)a.planes);
+    const size_t lds = (size_t)a.tile * (a.pl.m | 1) * sizeof(float2);
+    if (inverse) hipLaunchKernelGGL(fft_cols_kernel<true>, grid, dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL(fft_cols_kernel<false>, grid, dim3(kThreads), lds, s, a);
+    return vfi::check_launch("fft column pass");
+}
+
+}  // namespace fft
+}  // namespace vfi

@@ -22,8 +22,7 @@
 // index order so every table read is coalesced with the spectrum access; a thread owns one frequency bin
 // and loops over the N images, so tables are read once per level, not once per image.
 #include "vfi_common.h"
-
-#include <hipfft/hipfft.h>
+#include "vfi_fft.h"
 
 #include <cmath>
 #include <map>
@@ -57,8 +56,7 @@ struct vfi_pyr_plan {
     float2 *half_hi = nullptr;   // N x H x (W/2+1)   high-pass half spectrum (C2R input)
     float2 *bands = nullptr;     // N x nb x H x W    band spectra / coefficients of the current level
     float2 *lod[2] = {nullptr, nullptr};   // N x H x W each: running low-pass spectrum (ping-pong)
-    std::map<std::pair<int, int>, hipfftHandle> c2c;  // (level or -1 = low, -2 = full; batch)
-    std::map<int, hipfftHandle> r2c, c2r;
+    std::map<int, vfi::fft::Plan1D> fft1d;   // transform length -> tables (vfi_fft.h)
     std::vector<void *> allocs;
     // kept for vfi_pyr_plan_prepare_filter
     std::vector<double> log_rad, xr0, yr, yir;
@@ -379,39 +377,57 @@ __global__ void pyr_gain_kernel(float2 *__restrict__ half, const float *__restri
     }
 }
 
-// ---- FFT plan cache ---------------------------------------------------------------------------------------
-int get_c2c(vfi_pyr_plan *p, int key, int h, int w, int batch, hipfftHandle *out) {
-    auto it = p->c2c.find({key, batch});
-    if (it != p->c2c.end()) { *out = it->second; return VFI_OK; }
-    hipfftHandle hnd;
-    int n[2] = {h, w};
-    hipfftResult r = hipfftPlanMany(&hnd, 2, n, nullptr, 1, h * w, nullptr, 1, h * w, HIPFFT_C2C, batch);
-    if (r != HIPFFT_SUCCESS) return vfi::fail(VFI_ERR_FFT, "hipfftPlanMany C2C %dx%d batch %d: %d", h, w, batch, (int)r);
-    p->c2c[{key, batch}] = hnd;
-    *out = hnd;
+// ---- 2-D transforms = a row pass and a column pass of the LDS engine (vfi_fft.h / vfi_fft.hip) ---------------------------
+int get_fft(vfi_pyr_plan *p, int n, vfi::fft::Plan1D *out) {
+    auto it = p->fft1d.find(n);
+    if (it == p->fft1d.end()) {
+        vfi::fft::Plan1D pl;
+        const int rc = vfi::fft::make_plan(n, &pl, [](void *ctx, void *dev) { static_cast<vfi_pyr_plan *>(ctx)->allocs.push_back(dev); }, p);
+        if (rc) return rc;
+        it = p->fft1d.emplace(n, pl).first;
+    }
+    *out = it->second;
     return VFI_OK;
 }
-int get_real(vfi_pyr_plan *p, bool forward, int batch, hipfftHandle *out) {
-    auto &m = forward ? p->r2c : p->c2r;
-    auto it = m.find(batch);
-    if (it != m.end()) { *out = it->second; return VFI_OK; }
-    hipfftHandle hnd;
-    int n[2] = {p->H, p->W};
+
+// in-place complex 2-D transform of `planes` dense h x w arrays (un-normalised)
+int fft2d_c2c(vfi_pyr_plan *p, float2 *data, int planes, int h, int w, bool inverse, hipStream_t s) {
+    using namespace vfi::fft;
+    Plan1D ph, pw;
+    int rc;
+    if ((rc = get_fft(p, h, &ph)) || (rc = get_fft(p, w, &pw))) return rc;
+    ColArgs c{ph, data, planes, w, w, cols_per_group(ph, w), 1.0f};
+    if ((rc = launch_cols(c, inverse, s))) return rc;
+    const long long rows = (long long)planes * h;
+    RowArgs r{pw, data, data, rows, w, w, rows_per_group(pw, rows), 1.0f};
+    return launch_rows(r, kLoadComplex, kStoreComplex, inverse, s);
+}
+// real H x W images -> half spectra N x H x (W/2+1)
+int fft2d_r2c(vfi_pyr_plan *p, const float *img, float2 *half, int N, hipStream_t s) {
+    using namespace vfi::fft;
+    Plan1D ph, pw;
+    int rc;
+    if ((rc = get_fft(p, p->H, &ph)) || (rc = get_fft(p, p->W, &pw))) return rc;
     const int wh = p->W / 2 + 1;
-    hipfftResult r = forward
-        ? hipfftPlanMany(&hnd, 2, n, nullptr, 1, p->H * p->W, nullptr, 1, p->H * wh, HIPFFT_R2C, batch)
-        : hipfftPlanMany(&hnd, 2, n, nullptr, 1, p->H * wh, nullptr, 1, p->H * p->W, HIPFFT_C2R, batch);
-    if (r != HIPFFT_SUCCESS) return vfi::fail(VFI_ERR_FFT, "hipfftPlanMany %s %dx%d batch %d: %d", forward ? "R2C" : "C2R",
-                                              p->H, p->W, batch, (int)r);
-    m[batch] = hnd;
-    *out = hnd;
-    return VFI_OK;
+    const long long rows = (long long)N * p->H;
+    RowArgs r{pw, img, half, rows, p->W, wh, rows_per_group(pw, rows), 1.0f};
+    if ((rc = launch_rows(r, kLoadReal, kStoreHalf, false, s))) return rc;
+    ColArgs c{ph, half, N, wh, wh, cols_per_group(ph, wh), 1.0f};
+    return launch_cols(c, false, s);
 }
-#define FFT_CHECK(expr, what)                                                              \
-    do {                                                                                   \
-        hipfftResult r_ = (expr);                                                          \
-        if (r_ != HIPFFT_SUCCESS) return vfi::fail(VFI_ERR_FFT, "%s: hipfft error %d", what, (int)r_); \
-    } while (0)
+// half spectra (destroyed) -> real images, un-normalised inverse
+int fft2d_c2r(vfi_pyr_plan *p, float2 *half, float *out, int N, hipStream_t s) {
+    using namespace vfi::fft;
+    Plan1D ph, pw;
+    int rc;
+    if ((rc = get_fft(p, p->H, &ph)) || (rc = get_fft(p, p->W, &pw))) return rc;
+    const int wh = p->W / 2 + 1;
+    ColArgs c{ph, half, N, wh, wh, cols_per_group(ph, wh), 1.0f};
+    if ((rc = launch_cols(c, true, s))) return rc;
+    const long long rows = (long long)N * p->H;
+    RowArgs r{pw, half, out, rows, wh, p->W, rows_per_group(pw, rows), 1.0f};
+    return launch_rows(r, kLoadHalf, kStoreReal, true, s);
+}
 
 PlaneMap make_map(const int *plane_index, int level, int N, int nb, int flags) {
     PlaneMap pm;
@@ -447,6 +463,13 @@ extern "C" int vfi_pyr_plan_create(int H, int W, int height, int nbands, double 
     int rc = VFI_OK;
     if (p->hl < 2 || p->wl < 2) rc = vfi::fail(VFI_ERR_SHAPE, "vfi_pyr_plan_create: height %d too large for %dx%d", height, H, W);
     if (!rc) rc = build_tables(p);
+    {   // FFT tables of every length the plan can meet (so that no later call allocates)
+        vfi::fft::Plan1D tmp;
+        for (int k = 0; k <= p->nlev && !rc; ++k) {
+            rc = get_fft(p, k < p->nlev ? p->lev[k].h : p->hl, &tmp);
+            if (!rc) rc = get_fft(p, k < p->nlev ? p->lev[k].w : p->wl, &tmp);
+        }
+    }
     const size_t N = max_images, HW = (size_t)H * W, half = (size_t)H * (W / 2 + 1);
     if (!rc) rc = dev_alloc(p, (void **)&p->half0, N * half * sizeof(float2));
     if (!rc) rc = dev_alloc(p, (void **)&p->half_hi, N * half * sizeof(float2));
@@ -502,24 +525,16 @@ extern "C" int vfi_pyr_apply_filter(vfi_pyr_plan *p, int filter_id, const float 
     VFI_REQUIRE(filter_id >= 0 && filter_id < (int)p->filters.size(), VFI_ERR_INVALID_ARG, "vfi_pyr_apply_filter: bad filter id %d", filter_id);
     VFI_REQUIRE(N >= 1 && N <= p->max_images, VFI_ERR_INVALID_ARG, "vfi_pyr_apply_filter: N=%d (plan max %d)", N, p->max_images);
     hipStream_t s = vfi::as_stream(stream);
-    hipfftHandle f;
     int rc;
-    if ((rc = get_real(p, true, N, &f))) return rc;
-    FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_apply_filter");
-    FFT_CHECK(hipfftExecR2C(f, const_cast<float *>(img), reinterpret_cast<hipfftComplex *>(p->half0)), "vfi_pyr_apply_filter R2C");
+    if ((rc = fft2d_r2c(p, img, p->half0, N, s))) return rc;
     const long long per = (long long)p->H * (p->W / 2 + 1);
     hipLaunchKernelGGL(pyr_gain_kernel, dim3(blocks_1d(per * N)), dim3(256), 0, s, p->half0, p->filters[filter_id], N, per);
-    if ((rc = get_real(p, false, N, &f))) return rc;
-    FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_apply_filter");
-    FFT_CHECK(hipfftExecC2R(f, reinterpret_cast<hipfftComplex *>(p->half0), out), "vfi_pyr_apply_filter C2R");
+    if ((rc = fft2d_c2r(p, p->half0, out, N, s))) return rc;
     return vfi::check_launch("vfi_pyr_apply_filter");
 }
 
 extern "C" int vfi_pyr_plan_destroy(vfi_pyr_plan *p) {
     if (!p) return VFI_OK;
-    for (auto &kv : p->c2c) hipfftDestroy(kv.second);
-    for (auto &kv : p->r2c) hipfftDestroy(kv.second);
-    for (auto &kv : p->c2r) hipfftDestroy(kv.second);
     for (void *d : p->allocs) (void)hipFree(d);
     delete p;
     return VFI_OK;
@@ -542,11 +557,8 @@ extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *
                 "vfi_pyr_analyze: null phase/amp tables");
     hipStream_t s = vfi::as_stream(stream);
     const int H = p->H, W = p->W, nb = p->nbands;
-    hipfftHandle f;
     int rc;
-    if ((rc = get_real(p, true, N, &f))) return rc;
-    FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_analyze");
-    FFT_CHECK(hipfftExecR2C(f, const_cast<float *>(img), reinterpret_cast<hipfftComplex *>(p->half0)), "vfi_pyr_analyze R2C");
+    if ((rc = fft2d_r2c(p, img, p->half0, N, s))) return rc;
     const float2 *src = p->half0;
     for (int k = 0; k < p->nlev; ++k) {
         const Level &L = p->lev[k];
@@ -563,10 +575,7 @@ extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *
             hipLaunchKernelGGL((pyr_analysis_level_kernel<false, 4>), grid, dim3(256), 0, s, src, p->bands, next, nullptr,
                                L.P_a, L.lomask, nullptr, nullptr, N, L.h, L.w, h2, w2, wb, 0.0f);
         if (wb) {
-            if ((rc = get_c2c(p, k, L.h, L.w, N * nb, &f))) return rc;
-            FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_analyze");
-            FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(p->bands), reinterpret_cast<hipfftComplex *>(p->bands),
-                                    HIPFFT_BACKWARD), "vfi_pyr_analyze band IFFT");
+            if ((rc = fft2d_c2c(p, p->bands, N * nb, L.h, L.w, true, s))) return rc;
             const int hw = L.h * L.w;
             hipLaunchKernelGGL((pyr_polar_kernel<4>), dim3(ceil_div(hw, 256), N * nb), dim3(256), 0, s, p->bands, phase[k],
                                amp ? amp[k] : nullptr, make_map(plane_index, k, N, nb, flags), N, hw, 1.0f / (float)hw,
@@ -575,19 +584,14 @@ extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *
         src = next;
     }
     if (low) {  // low residual: real(ifft2(lodft))
-        if ((rc = get_c2c(p, -1, p->hl, p->wl, N, &f))) return rc;
-        FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_analyze");
         float2 *buf = const_cast<float2 *>(src);
-        FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(buf), reinterpret_cast<hipfftComplex *>(buf), HIPFFT_BACKWARD),
-                  "vfi_pyr_analyze low IFFT");
+        if ((rc = fft2d_c2c(p, buf, N, p->hl, p->wl, true, s))) return rc;
         const long long tot = (long long)N * p->hl * p->wl;
         hipLaunchKernelGGL(complex_real_kernel, dim3(blocks_1d(tot)), dim3(256), 0, s, buf, low, tot,
                            1.0f / ((float)p->hl * (float)p->wl));
     }
     if (high) {  // high residual: C2R of half * hi0 / (H W)
-        if ((rc = get_real(p, false, N, &f))) return rc;
-        FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_analyze");
-        FFT_CHECK(hipfftExecC2R(f, reinterpret_cast<hipfftComplex *>(p->half_hi), high), "vfi_pyr_analyze C2R");
+        if ((rc = fft2d_c2r(p, p->half_hi, high, N, s))) return rc;
     }
     return vfi::check_launch("vfi_pyr_analyze");
 }
@@ -601,19 +605,13 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
                 "vfi_pyr_synthesize: null phase/amp tables");
     hipStream_t s = vfi::as_stream(stream);
     const int H = p->H, W = p->W, nb = p->nbands;
-    hipfftHandle f;
     int rc;
     // coarsest: res = FFT(low) (zeros when low is NULL)
     float2 *res = p->lod[p->nlev & 1];
     {
         const long long tot = (long long)N * p->hl * p->wl;
         hipLaunchKernelGGL(real_to_complex_kernel, dim3(blocks_1d(tot)), dim3(256), 0, s, low, res, tot);
-        if (low) {
-            if ((rc = get_c2c(p, -1, p->hl, p->wl, N, &f))) return rc;
-            FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_synthesize");
-            FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(res), reinterpret_cast<hipfftComplex *>(res), HIPFFT_FORWARD),
-                      "vfi_pyr_synthesize low FFT");
-        }
+        if (low && (rc = fft2d_c2c(p, res, N, p->hl, p->wl, false, s))) return rc;
     }
     for (int k = p->nlev - 1; k >= 0; --k) {
         const Level &L = p->lev[k];
@@ -625,10 +623,7 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
                         "vfi_pyr_synthesize: null input for level %d", k);
             hipLaunchKernelGGL((pyr_to_complex_kernel<4>), dim3(ceil_div(hw, 256), N * nb), dim3(256), 0, s, phase[k],
                                amp ? amp[k] : nullptr, p->bands, make_map(plane_index, k, N, nb, flags), N, hw);
-            if ((rc = get_c2c(p, k, L.h, L.w, N * nb, &f))) return rc;
-            FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_synthesize");
-            FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(p->bands), reinterpret_cast<hipfftComplex *>(p->bands),
-                                    HIPFFT_FORWARD), "vfi_pyr_synthesize band FFT");
+            if ((rc = fft2d_c2c(p, p->bands, N * nb, L.h, L.w, false, s))) return rc;
         }
         float2 *cur = p->lod[k & 1];
         hipLaunchKernelGGL((pyr_combine_kernel<4>), dim3(ceil_div(L.w, 256), L.h), dim3(256), 0, s, p->bands, res, cur, L.P_s,
@@ -637,16 +632,11 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
     }
     const float2 *hi_half = nullptr;
     if (high) {
-        if ((rc = get_real(p, true, N, &f))) return rc;
-        FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_synthesize");
-        FFT_CHECK(hipfftExecR2C(f, const_cast<float *>(high), reinterpret_cast<hipfftComplex *>(p->half0)), "vfi_pyr_synthesize R2C");
+        if ((rc = fft2d_r2c(p, high, p->half0, N, s))) return rc;
         hi_half = p->half0;
     }
     hipLaunchKernelGGL(pyr_final_kernel, dim3(ceil_div(W, 256), H), dim3(256), 0, s, res, hi_half, p->lo0, p->hi0, N, H, W);
-    if ((rc = get_c2c(p, -2, H, W, N, &f))) return rc;
-    FFT_CHECK(hipfftSetStream(f, s), "vfi_pyr_synthesize");
-    FFT_CHECK(hipfftExecC2C(f, reinterpret_cast<hipfftComplex *>(res), reinterpret_cast<hipfftComplex *>(res), HIPFFT_BACKWARD),
-              "vfi_pyr_synthesize final IFFT");
+    if ((rc = fft2d_c2c(p, res, N, H, W, true, s))) return rc;
     const long long tot = (long long)N * H * W;
     hipLaunchKernelGGL(complex_real_kernel, dim3(blocks_1d(tot)), dim3(256), 0, s, res, img, tot, 1.0f / ((float)H * (float)W));
     return vfi::check_launch("vfi_pyr_synthesize");

@@ -1,0 +1,124 @@
+// Host-side check of the LDS FFT engine (csrc/vfi_fft.h): the very same gather / scatter / Bluestein index arithmetic the
+// device runs, executed on the CPU by looping over the 256 "threads" between the synchronisation points, against a
+// double-precision O(n^2) DFT.  Built and run by tests/test_fft_host.py (hipcc --cuda-host-only: no GPU involved).
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "vfi_fft.h"
+
+using namespace vfi::fft;
+using cd = std::complex<double>;
+
+struct HostPlan {
+    Plan1D pl;
+    std::vector<float2> tw, chirp, bfilt;
+};
+
+static void build(HostPlan &hp, int n) {
+    Plan1D &pl = hp.pl;
+    pl.n = n;
+    pl.bluestein = !factor_smooth(n, pl.radix, &pl.nstages);
+    pl.m = pl.bluestein ? bluestein_length(n) : n;
+    if (pl.bluestein && !factor_smooth(pl.m, pl.radix, &pl.nstages)) { std::printf("plan failed for %d\n", n); std::exit(2); }
+    hp.tw.resize(pl.m);
+    for (int k = 0; k < pl.m; ++k) hp.tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / pl.m), (float)std::sin(-2.0 * M_PI * k / pl.m));
+    pl.tw = hp.tw.data();
+    if (pl.bluestein) {
+        std::vector<cd> w(n), b(pl.m, cd(0, 0)), B(pl.m);
+        for (int j = 0; j < n; ++j) {
+            const long long e = ((long long)j * j) % (2LL * n);
+            w[j] = std::polar(1.0, -M_PI * (double)e / n);
+        }
+        b[0] = std::conj(w[0]);
+        for (int j = 1; j < n; ++j) b[j] = b[pl.m - j] = std::conj(w[j]);
+        for (int k = 0; k < pl.m; ++k) {           // O(M^2) is fine for a test
+            cd s(0, 0);
+            for (int j = 0; j < pl.m; ++j) s += b[j] * std::polar(1.0, -2.0 * M_PI * (double)((long long)j * k % pl.m) / pl.m);
+            B[k] = s / (double)pl.m;
+        }
+        hp.chirp.resize(n); hp.bfilt.resize(pl.m);
+        for (int j = 0; j < n; ++j) hp.chirp[j] = make_float2((float)w[j].real(), (float)w[j].imag());
+        for (int k = 0; k < pl.m; ++k) hp.bfilt[k] = make_float2((float)B[k].real(), (float)B[k].imag());
+        pl.chirp = hp.chirp.data(); pl.bfilt = hp.bfilt.data();
+    }
+}
+
+template <int R, bool INV>
+static void host_stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *tw) {
+    std::vector<StageRegs<R>> regs(kThreads);
+    for (int t = 0; t < kThreads; ++t) stage_gather<R, INV>(regs[t], t, buf, lines, pitch, m, p, tw);
+    for (int t = 0; t < kThreads; ++t) stage_scatter<R>(regs[t], t, buf, lines, pitch, m, p);
+}
+template <bool INV>
+static void host_stages(float2 *buf, int lines, int pitch, const Plan1D &pl) {
+    int p = 1;
+    for (int s = 0; s < pl.nstages; ++s) {
+        switch (pl.radix[s]) {
+            case 16: host_stage<16, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            case 8: host_stage<8, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            case 4: host_stage<4, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            case 2: host_stage<2, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            case 3: host_stage<3, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+            default: host_stage<5, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
+        }
+        p *= pl.radix[s];
+    }
+}
+template <bool INV>
+static void host_fft(float2 *buf, int lines, int pitch, const Plan1D &pl) {
+    if (!pl.bluestein) { host_stages<INV>(buf, lines, pitch, pl); return; }
+    for (int t = 0; t < kThreads; ++t) bluestein_pre<INV>(t, buf, lines, pitch, pl);
+    host_stages<false>(buf, lines, pitch, pl);
+    for (int t = 0; t < kThreads; ++t) bluestein_mid<INV>(t, buf, lines, pitch, pl);
+    host_stages<true>(buf, lines, pitch, pl);
+    for (int t = 0; t < kThreads; ++t) bluestein_post<INV>(t, buf, lines, pitch, pl);
+}
+
+static double check(int n, int lines, bool inv) {
+    HostPlan hp;
+    build(hp, n);
+    if (lines > max_lines(hp.pl)) lines = max_lines(hp.pl);
+    const int pitch = hp.pl.m + (lines > 1 ? 1 : 0);      // the column passes use an odd pitch
+    std::vector<float2> buf((size_t)lines * pitch, make_float2(7.0f, 7.0f));
+    std::vector<cd> x((size_t)lines * n);
+    unsigned s = 12345u + n;
+    for (auto &v : x) {
+        s = s * 1664525u + 1013904223u; const double a = (double)(s >> 8) / (1 << 24) - 0.5;
+        s = s * 1664525u + 1013904223u; const double b = (double)(s >> 8) / (1 << 24) - 0.5;
+        v = cd(a, b);
+    }
+    for (int l = 0; l < lines; ++l)
+        for (int j = 0; j < n; ++j) buf[(size_t)l * pitch + j] = make_float2((float)x[(size_t)l * n + j].real(), (float)x[(size_t)l * n + j].imag());
+    if (inv) host_fft<true>(buf.data(), lines, pitch, hp.pl); else host_fft<false>(buf.data(), lines, pitch, hp.pl);
+    double worst = 0, scale = 0;
+    for (int l = 0; l < lines; ++l)
+        for (int k = 0; k < n; ++k) {
+            cd acc(0, 0);
+            for (int j = 0; j < n; ++j) {
+                const cd xv((float)x[(size_t)l * n + j].real(), (float)x[(size_t)l * n + j].imag());
+                acc += xv * std::polar(1.0, (inv ? 2.0 : -2.0) * M_PI * (double)((long long)j * k % n) / n);
+            }
+            const float2 g = buf[(size_t)l * pitch + k];
+            worst = std::fmax(worst, std::abs(acc - cd(g.x, g.y)));
+            scale = std::fmax(scale, std::abs(acc));
+        }
+    return worst / scale;
+}
+
+int main() {
+    const int sizes[] = {2, 3, 4, 5, 6, 8, 9, 11, 12, 15, 16, 17, 22, 24, 30, 32, 43, 48, 60, 64, 65, 68, 77, 85, 90, 96, 120, 128,
+                         135, 170, 182, 191, 240, 256, 270, 340, 382, 480, 512, 540, 679, 720, 764, 905, 960, 1024, 1080, 1280,
+                         1358, 1920, 2048, 4096};
+    int bad = 0;
+    for (int n : sizes)
+        for (int inv = 0; inv < 2; ++inv) {
+            const double e = check(n, 3, inv);
+            const bool ok = e < 2e-6;
+            if (!ok) ++bad;
+            std::printf("n=%d %s rel.err %.2e %s\n", n, inv ? "inv" : "fwd", e, ok ? "" : "FAIL");
+        }
+    return bad ? 1 : 0;
+}
