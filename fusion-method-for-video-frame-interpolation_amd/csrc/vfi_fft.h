@@ -28,7 +28,9 @@ namespace vfi {
 namespace fft {
 
 constexpr int kThreads = 256;
-constexpr int kMaxElems = 8192;      // complex values of all lines of one workgroup (64 KiB of LDS)
+constexpr int kMaxElems = 8704;      // complex values of all lines of one workgroup (8 columns of a 1080-row level)
+constexpr int kMaxElemsB = 8192;     // ... when the plan is a Bluestein plan (its spectral product needs more registers)
+constexpr int kLdsElems = 9216;      // LDS elements incl. padding (72 KiB: two workgroups per CU)
 constexpr int kMaxStages = 8;
 
 struct Plan1D {                      // plain data, passed to kernels by value
@@ -143,49 +145,78 @@ template <bool INV> struct Dft<16, INV> {
 // an integer is >= 0.5 / d, far above the rounding error)
 VFI_HD int fast_div(int t, float inv_d) { return (int)(((float)t + 0.5f) * inv_d); }
 
+// LDS layout of a line: one pad element after every 32 (a stage's scatter with a small stride -- stage 0 writes
+// y[i*R + r] -- would otherwise put 32 lanes on one bank pair)
+VFI_HD int phys(int a) { return a + (a >> 5); }
+VFI_HD int padded_length(int m) { return m + ((m + 31) >> 5); }
+
 template <int R> struct StageRegs {
     static constexpr int QB = ((kMaxElems + R - 1) / R + kThreads - 1) / kThreads;   // butterflies per thread
+    static constexpr int QBB = ((kMaxElemsB + R - 1) / R + kThreads - 1) / kThreads;  // ... of a Bluestein plan
+    static constexpr int NW = R > 8 ? 4 : (R > 4 ? 3 : (R > 2 ? 2 : 1));              // twiddles loaded per butterfly
     float2 v[QB][R];
 };
 
-// ---- one Stockham stage, in two halves around a workgroup synchronisation -----------------------------------------
-template <int R, bool INV>
+// ---- one Stockham stage (FORWARD transform), in two halves around a workgroup synchronisation -------------------------
+// The engine only runs forward stages: an inverse transform is conj(FFT(conj(x))), and the callers conjugate while they
+// fill / drain the lines (free).  That halves the code.
+// MULB: the inputs are replaced by conj(x * bfilt[index]) on the way in -- Bluestein's spectral product and the
+// conjugation that turns the second forward transform into the inverse one, folded into its first stage.
+// All loads of all of a thread's butterflies (LDS operands, twiddles, filter) are issued before any arithmetic, so their
+// latencies overlap; out-of-range butterflies read butterfly 0 and are dropped by the scatter.
+template <int R, bool MULB>
 VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines, int pitch, int m, int p,
-                         const float2 *__restrict__ tw) {
+                         const float2 *__restrict__ tw, const float2 *__restrict__ bfilt) {
+    constexpr int QB = MULB ? StageRegs<R>::QBB : StageRegs<R>::QB, NW = StageRegs<R>::NW;
     const int T = m / R, total = lines * T, twstep = m / (p * R);
     const float inv_T = 1.0f / (float)T, inv_p = 1.0f / (float)p;
+    float2 w[QB][NW];
+    float2 bf[MULB ? QB : 1][MULB ? R : 1];
 #pragma unroll
-    for (int q = 0; q < StageRegs<R>::QB; ++q) {
-        const int t = tid + kThreads * q;
-        if (t < total) {
+    for (int q = 0; q < QB; ++q) {
+        if (kThreads * q < total) {                    // (uniform)
+            const int t0 = tid + kThreads * q, t = t0 < total ? t0 : 0;
             const int line = fast_div(t, inv_T), i = t - line * T, k = i - fast_div(i, inv_p) * p;
-            const float2 *x = buf + line * pitch + i;
+            const float2 *x = buf + line * pitch;
 #pragma unroll
-            for (int r = 0; r < R; ++r) s.v[q][r] = x[r * T];
-            if (p > 1) {                       // (first stage: every twiddle is 1)
-                const int e = k * twstep;      // r * e < m for r < R
-                float2 w[R];
-                w[1] = tw[e];
-                if (R > 2) w[2] = tw[2 * e];
-                if (R > 4) w[4] = tw[4 * e];
-                if (R > 8) w[8] = tw[8 * e];
-                if (INV) {
-                    w[1] = cconj(w[1]);
-                    if (R > 2) w[2] = cconj(w[2]);
-                    if (R > 4) w[4] = cconj(w[4]);
-                    if (R > 8) w[8] = cconj(w[8]);
-                }
-                if (R > 3) w[3] = cmul(w[1], w[2]);
-                if (R > 5) { w[5] = cmul(w[4], w[1]); }
-                if (R > 6) { w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]); }
-                if (R > 9) {
-                    w[9] = cmul(w[8], w[1]); w[10] = cmul(w[8], w[2]); w[11] = cmul(w[8], w[3]); w[12] = cmul(w[8], w[4]);
-                    w[13] = cmul(w[8], w[5]); w[14] = cmul(w[8], w[6]); w[15] = cmul(w[8], w[7]);
-                }
+            for (int r = 0; r < R; ++r) s.v[q][r] = x[phys(i + r * T)];
+            if (MULB) {
 #pragma unroll
-                for (int r = 1; r < R; ++r) s.v[q][r] = cmul(s.v[q][r], w[r]);
+                for (int r = 0; r < R; ++r) bf[MULB ? q : 0][MULB ? r : 0] = bfilt[i + r * T];
             }
-            Dft<R, INV>::run(s.v[q]);
+            if (p > 1) {                               // (first stage: every twiddle is 1)
+                const int e = k * twstep;              // r * e < m for r < R
+                w[q][0] = tw[e];
+                if (NW > 1) w[q][1] = tw[2 * e];
+                if (NW > 2) w[q][2] = tw[4 * e];
+                if (NW > 3) w[q][3] = tw[8 * e];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        if (kThreads * q < total) {
+            if (MULB) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) s.v[q][r] = cconj(cmul(s.v[q][r], bf[MULB ? q : 0][MULB ? r : 0]));
+            }
+            if (p > 1) {
+                float2 wr[R > 2 ? R : 3];
+                wr[1] = w[q][0];
+                if (R > 2) wr[2] = w[q][NW > 1 ? 1 : 0];
+                if (R > 4) wr[4] = w[q][NW > 2 ? 2 : 0];
+                if (R > 8) wr[8] = w[q][NW > 3 ? 3 : 0];
+                if (R > 3) wr[3] = cmul(wr[1], wr[2]);
+                if (R > 5) wr[5] = cmul(wr[4], wr[1]);
+                if (R > 6) { wr[6] = cmul(wr[4], wr[2]); wr[7] = cmul(wr[4], wr[3]); }
+                if (R > 9) {
+                    wr[9] = cmul(wr[8], wr[1]); wr[10] = cmul(wr[8], wr[2]); wr[11] = cmul(wr[8], wr[3]); wr[12] = cmul(wr[8], wr[4]);
+                    wr[13] = cmul(wr[8], wr[5]); wr[14] = cmul(wr[8], wr[6]); wr[15] = cmul(wr[8], wr[7]);
+                }
+#pragma unroll
+                for (int r = 1; r < R; ++r) s.v[q][r] = cmul(s.v[q][r], wr[r]);
+            }
+            Dft<R, false>::run(s.v[q]);
         }
     }
 }
@@ -199,84 +230,68 @@ VFI_HD void stage_scatter(const StageRegs<R> &s, int tid, float2 *buf, int lines
         const int t = tid + kThreads * q;
         if (t < total) {
             const int line = fast_div(t, inv_T), i = t - line * T, g = fast_div(i, inv_p), k = i - g * p;
-            float2 *y = buf + line * pitch + g * p * R + k;
+            float2 *y = buf + line * pitch;
+            const int a0 = g * p * R + k;
 #pragma unroll
-            for (int r = 0; r < R; ++r) y[r * p] = s.v[q][r];
+            for (int r = 0; r < R; ++r) y[phys(a0 + r * p)] = s.v[q][r];
         }
     }
 }
 
-// ---- element-wise steps of Bluestein's form ------------------------------------------------------------------------
-// buf[l][j] *= chirp[j] (conjugated for the inverse) for j < n, buf[l][j] = 0 for n <= j < m
-template <bool INV>
-VFI_HD void bluestein_pre(int tid, float2 *buf, int lines, int pitch, const Plan1D &pl) {
-    for (int l = 0; l < lines; ++l)
-        for (int j = tid; j < pl.m; j += kThreads) {
-            float2 z = make_float2(0.0f, 0.0f);
-            if (j < pl.n) {
-                float2 c = pl.chirp[j];
-                if (INV) c = cconj(c);
-                z = cmul(buf[l * pitch + j], c);
-            }
-            buf[l * pitch + j] = z;
-        }
+// ---- what the CALLER does while it fills / drains the lines ------------------------------------------------------------
+// fill : element j < n  <-  load_value<INV>(x[j], chirp[j])   (chirp ignored for smooth lengths); elements n <= j < m zero
+// drain: X[k]           =   store_value<INV>(line[k], chirp[k])
+// (inverse transforms by conjugation; Bluestein's chirp factors; the second transform of Bluestein's form leaves conj(Y).)
+template <bool INV> VFI_HD float2 load_value(float2 x, float2 chirp, bool bluestein) {
+    if (INV) x = cconj(x);
+    return bluestein ? cmul(x, chirp) : x;
 }
-template <bool INV>
-VFI_HD void bluestein_mid(int tid, float2 *buf, int lines, int pitch, const Plan1D &pl) {
-    for (int j = tid; j < pl.m; j += kThreads) {
-        float2 b = pl.bfilt[j];
-        if (INV) b = cconj(b);
-        for (int l = 0; l < lines; ++l) buf[l * pitch + j] = cmul(buf[l * pitch + j], b);
-    }
-}
-template <bool INV>
-VFI_HD void bluestein_post(int tid, float2 *buf, int lines, int pitch, const Plan1D &pl) {
-    for (int j = tid; j < pl.n; j += kThreads) {
-        float2 c = pl.chirp[j];
-        if (INV) c = cconj(c);
-        for (int l = 0; l < lines; ++l) buf[l * pitch + j] = cmul(buf[l * pitch + j], c);
-    }
+template <bool INV> VFI_HD float2 store_value(float2 b, float2 chirp, bool bluestein) {
+    if (bluestein) b = cmul(chirp, cconj(b));
+    return INV ? cconj(b) : b;
 }
 
-// ---- device entry: all 256 threads of the workgroup call it; buf must be filled and synchronised ----------------------
-template <int R, bool INV>
-__device__ __forceinline__ void stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *__restrict__ tw) {
+// ---- device entry: all 256 threads of the workgroup call it; the lines must be filled and synchronised -----------------
+// Stages are real function calls (one body per radix, shared by every kernel and every position in the stage list):
+// inlined, the ~10 unrolled bodies of a kernel made the register allocator spill kilobytes per lane.
+template <int R, bool MULB>
+__device__ __noinline__ void stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *__restrict__ tw,
+                                   const float2 *__restrict__ bfilt) {
     StageRegs<R> s;
-    stage_gather<R, INV>(s, threadIdx.x, buf, lines, pitch, m, p, tw);
+    stage_gather<R, MULB>(s, threadIdx.x, buf, lines, pitch, m, p, tw, bfilt);
     __syncthreads();
     stage_scatter<R>(s, threadIdx.x, buf, lines, pitch, m, p);
     __syncthreads();
 }
-template <bool INV>
-__device__ __forceinline__ void stages(float2 *buf, int lines, int pitch, const Plan1D &pl) {
-    int p = 1;
-    for (int s = 0; s < pl.nstages; ++s) {
-        switch (pl.radix[s]) {
-            case 16: stage<16, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
-            case 8: stage<8, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
-            case 4: stage<4, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
-            case 2: stage<2, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
-            case 3: stage<3, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
-            default: stage<5, INV>(buf, lines, pitch, pl.m, p, pl.tw); break;
-        }
-        p *= pl.radix[s];
+__device__ __forceinline__ void stage_any(int R, float2 *buf, int lines, int pitch, int m, int p, const float2 *tw) {
+    switch (R) {
+        case 16: stage<16, false>(buf, lines, pitch, m, p, tw, nullptr); break;
+        case 8: stage<8, false>(buf, lines, pitch, m, p, tw, nullptr); break;
+        case 4: stage<4, false>(buf, lines, pitch, m, p, tw, nullptr); break;
+        case 2: stage<2, false>(buf, lines, pitch, m, p, tw, nullptr); break;
+        case 3: stage<3, false>(buf, lines, pitch, m, p, tw, nullptr); break;
+        default: stage<5, false>(buf, lines, pitch, m, p, tw, nullptr); break;
     }
 }
-// `lines` transforms of length pl.n at buf[l * pitch + j] (pitch >= pl.m), results in place at [0, pl.n) of each line.
-template <bool INV>
+// `lines` FORWARD transforms at buf[l * pitch + phys(j)]; results in place (see load_value / store_value).
 __device__ __forceinline__ void fft_lines(float2 *buf, int lines, int pitch, const Plan1D &pl) {
-    if (!pl.bluestein) {
-        stages<INV>(buf, lines, pitch, pl);
-        return;
+    int p = 1;
+    for (int s = 0; s < pl.nstages; ++s) {
+        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw);
+        p *= pl.radix[s];
     }
-    bluestein_pre<INV>(threadIdx.x, buf, lines, pitch, pl);
-    __syncthreads();
-    stages<false>(buf, lines, pitch, pl);
-    bluestein_mid<INV>(threadIdx.x, buf, lines, pitch, pl);
-    __syncthreads();
-    stages<true>(buf, lines, pitch, pl);
-    bluestein_post<INV>(threadIdx.x, buf, lines, pitch, pl);
-    __syncthreads();
+    if (!pl.bluestein) return;
+    switch (pl.radix[0]) {                  // (a Bluestein length is a power of two: radices 16, 8, 4, 2 only)
+        case 16: stage<16, true>(buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt); break;
+        case 8: stage<8, true>(buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt); break;
+        case 4: stage<4, true>(buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt); break;
+        default: stage<2, true>(buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt); break;
+    }
+    p = pl.radix[0];
+    for (int s = 1; s < pl.nstages; ++s) {
+        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw);
+        p *= pl.radix[s];
+    }
 }
 
 // ---- host-side planning ----------------------------------------------------------------------------------------------
@@ -297,8 +312,16 @@ inline int bluestein_length(int n) {
     while (M < 2 * n - 1) M *= 2;
     return M;
 }
-// how many lines of this plan fit into one workgroup's buffer
-inline int max_lines(const Plan1D &pl) { return kMaxElems / pl.m; }
+// LDS line pitch: row passes store lines back to back; column passes fill `tile` lines with consecutive lanes going
+// ACROSS the lines, so the pitch is chosen = 32/tile (mod 32) elements: the lanes of one wave then cover all banks
+inline int row_pitch(const Plan1D &pl) { return padded_length(pl.m); }
+inline int col_pitch(const Plan1D &pl, int tile) { return ((padded_length(pl.m) + 31) & ~31) + (tile < 32 ? 32 / tile : 1); }
+inline int max_elems(const Plan1D &pl) { return pl.bluestein ? kMaxElemsB : kMaxElems; }
+// how many rows of this plan fit into one workgroup's buffer
+inline int max_lines(const Plan1D &pl) {
+    const int a = max_elems(pl) / pl.m, b = kLdsElems / row_pitch(pl);
+    return a < b ? a : b;
+}
 
 }  // namespace fft
 }  // namespace vfi
