@@ -30,7 +30,7 @@ namespace fft {
 constexpr int kThreads = 256;
 constexpr int kMaxElems = 8704;      // complex values of all lines of one workgroup (8 columns of a 1080-row level)
 constexpr int kMaxElemsB = 8192;     // ... when the plan is a Bluestein plan (its spectral product needs more registers)
-constexpr int kLdsElems = 9216;      // LDS elements incl. padding (72 KiB: two workgroups per CU)
+constexpr int kLdsElems = 9600;      // LDS elements incl. padding and the twiddle table (75 KiB: two workgroups per CU)
 constexpr int kMaxStages = 8;
 
 struct Plan1D {                      // plain data, passed to kernels by value
@@ -38,6 +38,7 @@ struct Plan1D {                      // plain data, passed to kernels by value
     int m;                           // length run through the stages: n (smooth) or the Bluestein length M
     int nstages, bluestein;
     int radix[kMaxStages];
+    int tw_len;                      // leading entries of `tw` a workgroup keeps in LDS
     const float2 *tw;                // m entries  exp(-2 pi i k / m)
     const float2 *chirp;             // n entries  exp(-i pi j^2 / n)            (Bluestein only)
     const float2 *bfilt;             // m entries  FFT_M(conj(chirp) wrapped) / M (Bluestein only)
@@ -141,9 +142,72 @@ template <bool INV> struct Dft<16, INV> {
     }
 };
 
+// composite radix R = R1 * R2 inside the registers (input index c + R1*r, output index q + R2*s):
+//   X[q + R2*s] = sum_c W_R1^(c*s) * W_R^(c*q) * (sum_r x[c + R1*r] * W_R2^(r*q))
+template <int R> struct Cis;       // exp(+2 pi i e / R) as {cos, sin}, e < R
+template <> struct Cis<9> {
+    static VFI_HD float2 at(int e) {
+        constexpr float t[9][2] = {{1.0f, 0.0f}, {0.76604444311897801345f, 0.64278760968653925190f}, {0.17364817766693041445f, 0.98480775301220802032f},
+                                   {-0.5f, 0.86602540378443864676f}, {-0.93969262078590831688f, 0.34202014332566887944f},
+                                   {-0.93969262078590831688f, -0.34202014332566887944f}, {-0.5f, -0.86602540378443864676f},
+                                   {0.17364817766693041445f, -0.98480775301220802032f}, {0.76604444311897801345f, -0.64278760968653925190f}};
+        return make_float2(t[e][0], t[e][1]);
+    }
+};
+template <> struct Cis<15> {
+    static VFI_HD float2 at(int e) {
+        constexpr float t[15][2] = {{1.0f, 0.0f}, {0.91354545764260086660f, 0.40673664307580015276f}, {0.66913060635885823757f, 0.74314482547739413310f},
+                                    {0.30901699437494745126f, 0.95105651629515353118f}, {-0.10452846326765333207f, 0.99452189536827340088f},
+                                    {-0.5f, 0.86602540378443864676f}, {-0.80901699437494734024f, 0.58778525229247324813f},
+                                    {-0.97814760073380568883f, 0.20791169081775931482f}, {-0.97814760073380568883f, -0.20791169081775931482f},
+                                    {-0.80901699437494734024f, -0.58778525229247324813f}, {-0.5f, -0.86602540378443864676f},
+                                    {-0.10452846326765333207f, -0.99452189536827340088f}, {0.30901699437494745126f, -0.95105651629515353118f},
+                                    {0.66913060635885823757f, -0.74314482547739413310f}, {0.91354545764260086660f, -0.40673664307580015276f}};
+        return make_float2(t[e][0], t[e][1]);
+    }
+};
+template <int R1, int R2, bool INV> struct DftComposite {
+    static VFI_HD void run(float2 *v) {
+        constexpr int R = R1 * R2;
+        float2 t[R1][R2];
+#pragma unroll
+        for (int c = 0; c < R1; ++c) {
+            float2 col[R2];
+#pragma unroll
+            for (int r = 0; r < R2; ++r) col[r] = v[c + R1 * r];
+            Dft<R2, INV>::run(col);
+#pragma unroll
+            for (int q = 0; q < R2; ++q) {
+                if (c * q == 0) { t[c][q] = col[q]; continue; }
+                const float2 w = Cis<R>::at((c * q) % R);      // forward: exp(-i..) = conj
+                t[c][q] = cmul(col[q], INV ? w : cconj(w));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R2; ++q) {
+            float2 row[R1];
+#pragma unroll
+            for (int c = 0; c < R1; ++c) row[c] = t[c][q];
+            Dft<R1, INV>::run(row);
+#pragma unroll
+            for (int s = 0; s < R1; ++s) v[q + R2 * s] = row[s];
+        }
+    }
+};
+template <bool INV> struct Dft<9, INV> { static VFI_HD void run(float2 *v) { DftComposite<3, 3, INV>::run(v); } };
+template <bool INV> struct Dft<15, INV> { static VFI_HD void run(float2 *v) { DftComposite<3, 5, INV>::run(v); } };
+
 // exact floor(t / d) for 0 <= t < 2^15, 1 <= d < 2^15 through a float reciprocal (the distance of (t + 0.5) / d from
 // an integer is >= 0.5 / d, far above the rounding error)
 VFI_HD int fast_div(int t, float inv_d) { return (int)(((float)t + 0.5f) * inv_d); }
+// products of small non-negative ints (< 2^23): full-rate v_mul_u32_u24 instead of the quarter-rate 32-bit multiply
+VFI_HD int mul24(int a, int b) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
 
 // LDS layout of a line: one pad element after every 32 (a stage's scatter with a small stride -- stage 0 writes
 // y[i*R + r] -- would otherwise put 32 lanes on one bank pair)
@@ -166,9 +230,11 @@ template <int R> struct StageRegs {
 // latencies overlap; out-of-range butterflies read butterfly 0 and are dropped by the scatter.
 template <int R, bool MULB>
 VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines, int pitch, int m, int p,
-                         const float2 *__restrict__ tw, const float2 *__restrict__ bfilt) {
+                         const float2 *tw, int tw_len, const float2 *__restrict__ bfilt) {
     constexpr int QB = MULB ? StageRegs<R>::QBB : StageRegs<R>::QB, NW = StageRegs<R>::NW;
     const int T = m / R, total = lines * T, twstep = m / (p * R);
+    // how many of W^e, W^2e, W^4e, W^8e (e < T) lie inside the LDS table; the others are formed by squaring (uniform)
+    const int nload = T <= tw_len ? (2 * T <= tw_len ? (4 * T <= tw_len ? (8 * T <= tw_len ? 4 : 3) : 2) : 1) : 0;
     const float inv_T = 1.0f / (float)T, inv_p = 1.0f / (float)p;
     float2 w[QB][NW];
     float2 bf[MULB ? QB : 1][MULB ? R : 1];
@@ -176,20 +242,20 @@ VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines,
     for (int q = 0; q < QB; ++q) {
         if (kThreads * q < total) {                    // (uniform)
             const int t0 = tid + kThreads * q, t = t0 < total ? t0 : 0;
-            const int line = fast_div(t, inv_T), i = t - line * T, k = i - fast_div(i, inv_p) * p;
-            const float2 *x = buf + line * pitch;
+            const int line = fast_div(t, inv_T), i = t - mul24(line, T), k = i - mul24(fast_div(i, inv_p), p);
+            const float2 *x = buf + mul24(line, pitch);
 #pragma unroll
-            for (int r = 0; r < R; ++r) s.v[q][r] = x[phys(i + r * T)];
+            for (int r = 0; r < R; ++r) s.v[q][r] = x[phys(i + mul24(r, T))];
             if (MULB) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) bf[MULB ? q : 0][MULB ? r : 0] = bfilt[i + r * T];
+                for (int r = 0; r < R; ++r) bf[MULB ? q : 0][MULB ? r : 0] = bfilt[i + mul24(r, T)];
             }
             if (p > 1) {                               // (first stage: every twiddle is 1)
-                const int e = k * twstep;              // r * e < m for r < R
+                const int e = mul24(k, twstep);        // e < T
                 w[q][0] = tw[e];
-                if (NW > 1) w[q][1] = tw[2 * e];
-                if (NW > 2) w[q][2] = tw[4 * e];
-                if (NW > 3) w[q][3] = tw[8 * e];
+                if (NW > 1 && nload > 1) w[q][1] = tw[2 * e];
+                if (NW > 2 && nload > 2) w[q][2] = tw[4 * e];
+                if (NW > 3 && nload > 3) w[q][3] = tw[8 * e];
             }
         }
     }
@@ -203,16 +269,17 @@ VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines,
             if (p > 1) {
                 float2 wr[R > 2 ? R : 3];
                 wr[1] = w[q][0];
-                if (R > 2) wr[2] = w[q][NW > 1 ? 1 : 0];
-                if (R > 4) wr[4] = w[q][NW > 2 ? 2 : 0];
-                if (R > 8) wr[8] = w[q][NW > 3 ? 3 : 0];
+                if (R > 2) wr[2] = nload > 1 ? w[q][NW > 1 ? 1 : 0] : cmul(wr[1], wr[1]);
+                if (R > 4) wr[4] = nload > 2 ? w[q][NW > 2 ? 2 : 0] : cmul(wr[2], wr[2]);
+                if (R > 8) wr[8] = nload > 3 ? w[q][NW > 3 ? 3 : 0] : cmul(wr[4], wr[4]);
                 if (R > 3) wr[3] = cmul(wr[1], wr[2]);
                 if (R > 5) wr[5] = cmul(wr[4], wr[1]);
                 if (R > 6) { wr[6] = cmul(wr[4], wr[2]); wr[7] = cmul(wr[4], wr[3]); }
                 if (R > 9) {
                     wr[9] = cmul(wr[8], wr[1]); wr[10] = cmul(wr[8], wr[2]); wr[11] = cmul(wr[8], wr[3]); wr[12] = cmul(wr[8], wr[4]);
-                    wr[13] = cmul(wr[8], wr[5]); wr[14] = cmul(wr[8], wr[6]); wr[15] = cmul(wr[8], wr[7]);
+                    wr[13] = cmul(wr[8], wr[5]); wr[14] = cmul(wr[8], wr[6]);
                 }
+                if (R > 15) wr[15] = cmul(wr[8], wr[7]);
 #pragma unroll
                 for (int r = 1; r < R; ++r) s.v[q][r] = cmul(s.v[q][r], wr[r]);
             }
@@ -229,11 +296,11 @@ VFI_HD void stage_scatter(const StageRegs<R> &s, int tid, float2 *buf, int lines
     for (int q = 0; q < StageRegs<R>::QB; ++q) {
         const int t = tid + kThreads * q;
         if (t < total) {
-            const int line = fast_div(t, inv_T), i = t - line * T, g = fast_div(i, inv_p), k = i - g * p;
-            float2 *y = buf + line * pitch;
-            const int a0 = g * p * R + k;
+            const int line = fast_div(t, inv_T), i = t - mul24(line, T), g = fast_div(i, inv_p), k = i - mul24(g, p);
+            float2 *y = buf + mul24(line, pitch);
+            const int a0 = mul24(g, mul24(p, R)) + k;
 #pragma unroll
-            for (int r = 0; r < R; ++r) y[phys(a0 + r * p)] = s.v[q][r];
+            for (int r = 0; r < R; ++r) y[phys(a0 + mul24(r, p))] = s.v[q][r];
         }
     }
 }
@@ -251,54 +318,105 @@ template <bool INV> VFI_HD float2 store_value(float2 b, float2 chirp, bool blues
     return INV ? cconj(b) : b;
 }
 
+// ---- filling / draining the lines: `total` elements, element e handled by thread e % 256 -------------------------------
+// Chunks of kChunk elements per thread: all global loads of a chunk are issued before the first use (their latencies
+// overlap), while the values in flight stay at a bounded number of registers.
+struct Slot { float2 z, c; float s; };
+constexpr int kChunk = 18;
+template <typename LoadF, typename UseF>
+__device__ __forceinline__ void for_slots(int total, LoadF load, UseF use) {
+    for (int q0 = 0; q0 * kThreads < total; q0 += kChunk) {      // (uniform trip count)
+        Slot v[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int e = (int)threadIdx.x + kThreads * (q0 + q);
+            if (kThreads * (q0 + q) < total) v[q] = load(e < total ? e : 0);
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int e = (int)threadIdx.x + kThreads * (q0 + q);
+            if (e < total) use(e, v[q]);
+        }
+    }
+}
+
 // ---- device entry: all 256 threads of the workgroup call it; the lines must be filled and synchronised -----------------
 // Stages are real function calls (one body per radix, shared by every kernel and every position in the stage list):
 // inlined, the ~10 unrolled bodies of a kernel made the register allocator spill kilobytes per lane.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding GLOBAL access
+// (s_waitcnt vmcnt(0)): with it, the stores of one band's drain would have to land before the next band could start.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int R, bool MULB>
-__device__ __noinline__ void stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *__restrict__ tw,
+__device__ __noinline__ void stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, int tw_len,
                                    const float2 *__restrict__ bfilt) {
     StageRegs<R> s;
-    stage_gather<R, MULB>(s, threadIdx.x, buf, lines, pitch, m, p, tw, bfilt);
-    __syncthreads();
+    stage_gather<R, MULB>(s, threadIdx.x, buf, lines, pitch, m, p, tw, tw_len, bfilt);
+    lds_barrier();
     stage_scatter<R>(s, threadIdx.x, buf, lines, pitch, m, p);
-    __syncthreads();
+    lds_barrier();
 }
-__device__ __forceinline__ void stage_any(int R, float2 *buf, int lines, int pitch, int m, int p, const float2 *tw) {
+__device__ __forceinline__ void stage_any(int R, float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, int tw_len) {
     switch (R) {
-        case 16: stage<16, false>(buf, lines, pitch, m, p, tw, nullptr); break;
-        case 8: stage<8, false>(buf, lines, pitch, m, p, tw, nullptr); break;
-        case 4: stage<4, false>(buf, lines, pitch, m, p, tw, nullptr); break;
-        case 2: stage<2, false>(buf, lines, pitch, m, p, tw, nullptr); break;
-        case 3: stage<3, false>(buf, lines, pitch, m, p, tw, nullptr); break;
-        default: stage<5, false>(buf, lines, pitch, m, p, tw, nullptr); break;
+        case 16: stage<16, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+        case 15: stage<15, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+        case 9: stage<9, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+        case 8: stage<8, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+        case 4: stage<4, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+        case 2: stage<2, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+        case 3: stage<3, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+        default: stage<5, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+    }
+}
+// The workgroup's copy of the twiddle table: pl.tw_len entries behind the lines (call once, before the first fft_lines;
+// the barrier that publishes the filled lines publishes it too).
+__device__ __forceinline__ void load_twiddles(float2 *twl, const Plan1D &pl) {
+    for (int k0 = 0; k0 < pl.tw_len; k0 += 4 * kThreads) {      // 4 loads in flight per thread
+        float2 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j * kThreads + (int)threadIdx.x;
+            t[j] = pl.tw[k < pl.tw_len ? k : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j * kThreads + (int)threadIdx.x;
+            if (k < pl.tw_len) twl[k] = t[j];
+        }
     }
 }
 // `lines` FORWARD transforms at buf[l * pitch + phys(j)]; results in place (see load_value / store_value).
-__device__ __forceinline__ void fft_lines(float2 *buf, int lines, int pitch, const Plan1D &pl) {
+// twl: the LDS twiddle table filled by load_twiddles.
+__device__ __forceinline__ void fft_lines(float2 *buf, int lines, int pitch, const Plan1D &pl, const float2 *twl) {
     int p = 1;
     for (int s = 0; s < pl.nstages; ++s) {
-        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw);
+        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, twl, pl.tw_len);
         p *= pl.radix[s];
     }
     if (!pl.bluestein) return;
     switch (pl.radix[0]) {                  // (a Bluestein length is a power of two: radices 16, 8, 4, 2 only)
-        case 16: stage<16, true>(buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt); break;
-        case 8: stage<8, true>(buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt); break;
-        case 4: stage<4, true>(buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt); break;
-        default: stage<2, true>(buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt); break;
+        case 16: stage<16, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt); break;
+        case 8: stage<8, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt); break;
+        case 4: stage<4, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt); break;
+        default: stage<2, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt); break;
     }
     p = pl.radix[0];
     for (int s = 1; s < pl.nstages; ++s) {
-        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw);
+        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, twl, pl.tw_len);
         p *= pl.radix[s];
     }
 }
 
 // ---- host-side planning ----------------------------------------------------------------------------------------------
-// radices for a smooth length (16s, then 8, 4, 2, then 3s and 5s); false when n has another prime factor
+// radices for a smooth length: as few, as large stages as possible (16, 15, 9, 8, then 5, 4, 3, 2); false when n has
+// another prime factor.  A power of two only gets powers of two (Bluestein's spectral product sits in its first stage).
 inline bool factor_smooth(int n, int *radix, int *nstages) {
     int m = n, ns = 0;
-    for (int r : {16, 8, 4, 2, 3, 5})
+    for (int r : {16, 15, 9, 8, 5, 4, 3, 2})
         while (m % r == 0) {
             if (ns >= kMaxStages) return false;
             radix[ns++] = r;
@@ -317,11 +435,18 @@ inline int bluestein_length(int n) {
 inline int row_pitch(const Plan1D &pl) { return padded_length(pl.m); }
 inline int col_pitch(const Plan1D &pl, int tile) { return ((padded_length(pl.m) + 31) & ~31) + (tile < 32 ? 32 / tile : 1); }
 inline int max_elems(const Plan1D &pl) { return pl.bluestein ? kMaxElemsB : kMaxElems; }
-// how many rows of this plan fit into one workgroup's buffer
+// LDS twiddle entries: half the table (a quarter for long powers of two); powers that fall outside are squared up
+inline int twiddle_entries(int m) { return (m % 4 == 0 && m >= 2048) ? m / 4 : (m + 1) / 2; }
+// how many rows of this plan fit into one workgroup's buffer (lines + twiddle table <= kLdsElems)
 inline int max_lines(const Plan1D &pl) {
-    const int a = max_elems(pl) / pl.m, b = kLdsElems / row_pitch(pl);
+    const int a = max_elems(pl) / pl.m, b = (kLdsElems - pl.tw_len) / row_pitch(pl);
     return a < b ? a : b;
 }
+// LDS bytes of a row / column pass (lines, the twiddle table, `extra` bytes of the caller's own)
+inline size_t row_lds_bytes(const Plan1D &pl, int lines, size_t extra = 0) {
+    return ((size_t)lines * row_pitch(pl) + pl.tw_len) * sizeof(float2) + extra;
+}
+inline size_t col_lds_bytes(const Plan1D &pl, int tile) { return ((size_t)tile * col_pitch(pl, tile) + pl.tw_len) * sizeof(float2); }
 
 }  // namespace fft
 }  // namespace vfi

@@ -41,77 +41,60 @@ void host_fft_pow2(std::vector<cd> &a) {       // in-place radix-2, forward, dou
     }
 }
 
-constexpr int kSlots = (kMaxElems + kThreads - 1) / kThreads;      // elements a thread moves per pass (34)
-
 template <int LOAD, int STORE, bool INV>
 __global__ __launch_bounds__(kThreads, 2) void fft_rows_kernel(const RowArgs a) {
     extern __shared__ float2 buf[];
     const int n = a.pl.n, m = a.pl.m, pitch = padded_length(m), tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * a.lines;
     const int lines = (int)(a.rows - row0 < a.lines ? a.rows - row0 : a.lines);
-    const int total = lines * n;
     const float inv_n = 1.0f / (float)n;
     const int wh = n / 2 + 1;
     const bool blu = a.pl.bluestein != 0;
-    {   // fill: all global loads first (their latencies overlap), then the LDS writes
-        float2 z[kSlots], c[kSlots];
-#pragma unroll
-        for (int q = 0; q < kSlots; ++q) {
-            if (kThreads * q < total) {
-                const int e0 = tid + kThreads * q, e = e0 < total ? e0 : 0;
-                const int l = fast_div(e, inv_n), j = e - l * n;
-                if (LOAD == kLoadComplex) {
-                    z[q] = static_cast<const float2 *>(a.src)[(row0 + l) * a.src_pitch + j];
-                } else if (LOAD == kLoadReal) {
-                    z[q] = make_float2(static_cast<const float *>(a.src)[(row0 + l) * a.src_pitch + j], 0.0f);
-                } else {
-                    const float2 *r = static_cast<const float2 *>(a.src) + (row0 + l) * a.src_pitch;
-                    z[q] = j < wh ? r[j] : cconj(r[n - j]);
-                }
-                if (blu) c[q] = a.pl.chirp[j];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < kSlots; ++q) {
-            const int e = tid + kThreads * q;
-            if (e < total) {
-                const int l = fast_div(e, inv_n), j = e - l * n;
-                buf[l * pitch + phys(j)] = load_value<INV>(z[q], c[q], blu);
-            }
-        }
-        if (blu) {                                     // zero padding [n, m)
-            const int pad = m - n, totz = lines * pad;
-            const float inv_pad = 1.0f / (float)pad;
-            for (int e = tid; e < totz; e += kThreads) {
-                const int l = fast_div(e, inv_pad), j = n + e - l * pad;
-                buf[l * pitch + phys(j)] = make_float2(0.0f, 0.0f);
-            }
+    float2 *twl = buf + (size_t)a.lines * pitch;
+    load_twiddles(twl, a.pl);
+    for_slots(lines * n,
+              [&](int e) {
+                  const int l = fast_div(e, inv_n), j = e - l * n;
+                  Slot v;
+                  if (LOAD == kLoadComplex) {
+                      v.z = static_cast<const float2 *>(a.src)[(row0 + l) * a.src_pitch + j];
+                  } else if (LOAD == kLoadReal) {
+                      v.z = make_float2(static_cast<const float *>(a.src)[(row0 + l) * a.src_pitch + j], 0.0f);
+                  } else {
+                      const float2 *r = static_cast<const float2 *>(a.src) + (row0 + l) * a.src_pitch;
+                      v.z = j < wh ? r[j] : cconj(r[n - j]);
+                  }
+                  if (blu) v.c = a.pl.chirp[j];
+                  return v;
+              },
+              [&](int e, const Slot &v) {
+                  const int l = fast_div(e, inv_n), j = e - l * n;
+                  buf[l * pitch + phys(j)] = load_value<INV>(v.z, v.c, blu);
+              });
+    if (blu) {                                     // zero padding [n, m)
+        const int pad = m - n, totz = lines * pad;
+        const float inv_pad = 1.0f / (float)pad;
+        for (int e = tid; e < totz; e += kThreads) {
+            const int l = fast_div(e, inv_pad), j = n + e - l * pad;
+            buf[l * pitch + phys(j)] = make_float2(0.0f, 0.0f);
         }
     }
-    __syncthreads();
-    fft_lines(buf, lines, pitch, a.pl);
+    lds_barrier();
+    fft_lines(buf, lines, pitch, a.pl, twl);
     const int nout = STORE == kStoreHalf ? wh : n;
     const float inv_o = 1.0f / (float)nout;
-    const int total_o = lines * nout;
-    float2 c[kSlots];
-    if (blu) {
-#pragma unroll
-        for (int q = 0; q < kSlots; ++q)
-            if (kThreads * q < total_o) {
-                const int e0 = tid + kThreads * q, e = e0 < total_o ? e0 : 0;
-                c[q] = a.pl.chirp[e - fast_div(e, inv_o) * nout];
-            }
-    }
-#pragma unroll
-    for (int q = 0; q < kSlots; ++q) {
-        const int e = tid + kThreads * q;
-        if (e < total_o) {
-            const int l = fast_div(e, inv_o), j = e - l * nout;
-            const float2 z = store_value<INV>(buf[l * pitch + phys(j)], c[q], blu);
-            if (STORE == kStoreReal) static_cast<float *>(a.dst)[(row0 + l) * a.dst_pitch + j] = z.x * a.scale;
-            else static_cast<float2 *>(a.dst)[(row0 + l) * a.dst_pitch + j] = make_float2(z.x * a.scale, z.y * a.scale);
-        }
-    }
+    for_slots(lines * nout,
+              [&](int e) {
+                  Slot v;
+                  if (blu) v.c = a.pl.chirp[e - fast_div(e, inv_o) * nout];
+                  return v;
+              },
+              [&](int e, const Slot &v) {
+                  const int l = fast_div(e, inv_o), j = e - l * nout;
+                  const float2 z = store_value<INV>(buf[l * pitch + phys(j)], v.c, blu);
+                  if (STORE == kStoreReal) static_cast<float *>(a.dst)[(row0 + l) * a.dst_pitch + j] = z.x * a.scale;
+                  else static_cast<float2 *>(a.dst)[(row0 + l) * a.dst_pitch + j] = make_float2(z.x * a.scale, z.y * a.scale);
+              });
 }
 
 template <bool INV>
@@ -124,55 +107,42 @@ __global__ __launch_bounds__(kThreads, 2) void fft_cols_kernel(const ColArgs a) 
     float2 *plane = a.data + (size_t)blockIdx.y * h * a.ld + v0;
     const int shift = __ffs(C) - 1, total = h * C;
     const bool blu = a.pl.bluestein != 0;
-    {
-        float2 z[kSlots], c[kSlots];
-#pragma unroll
-        for (int q = 0; q < kSlots; ++q) {
-            if (kThreads * q < total) {
-                const int e0 = tid + kThreads * q, e = e0 < total ? e0 : 0;
-                const int u = e >> shift, cc = e & (C - 1);
-                z[q] = plane[(size_t)u * a.ld + (cc < lines ? cc : 0)];
-                if (blu) c[q] = a.pl.chirp[u];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < kSlots; ++q) {
-            const int e = tid + kThreads * q;
-            if (e < total) {
-                const int u = e >> shift, cc = e & (C - 1);
-                if (cc < lines) buf[cc * pitch + phys(u)] = load_value<INV>(z[q], c[q], blu);
-            }
-        }
-        if (blu) {
-            const int pad = m - h, totz = pad * C;
-            for (int e = tid; e < totz; e += kThreads) {
-                const int u = h + (e >> shift), cc = e & (C - 1);
-                if (cc < lines) buf[cc * pitch + phys(u)] = make_float2(0.0f, 0.0f);
-            }
-        }
-    }
-    __syncthreads();
-    fft_lines(buf, lines, pitch, a.pl);
-    float2 c[kSlots];
+    float2 *twl = buf + (size_t)C * pitch;
+    load_twiddles(twl, a.pl);
+    for_slots(total,
+              [&](int e) {
+                  const int u = e >> shift, cc = e & (C - 1);
+                  Slot v;
+                  v.z = plane[(size_t)u * a.ld + (cc < lines ? cc : 0)];
+                  if (blu) v.c = a.pl.chirp[u];
+                  return v;
+              },
+              [&](int e, const Slot &v) {
+                  const int u = e >> shift, cc = e & (C - 1);
+                  if (cc < lines) buf[cc * pitch + phys(u)] = load_value<INV>(v.z, v.c, blu);
+              });
     if (blu) {
-#pragma unroll
-        for (int q = 0; q < kSlots; ++q)
-            if (kThreads * q < total) {
-                const int e0 = tid + kThreads * q, e = e0 < total ? e0 : 0;
-                c[q] = a.pl.chirp[e >> shift];
-            }
-    }
-#pragma unroll
-    for (int q = 0; q < kSlots; ++q) {
-        const int e = tid + kThreads * q;
-        if (e < total) {
-            const int u = e >> shift, cc = e & (C - 1);
-            if (cc < lines) {
-                const float2 z = store_value<INV>(buf[cc * pitch + phys(u)], c[q], blu);
-                plane[(size_t)u * a.ld + cc] = make_float2(z.x * a.scale, z.y * a.scale);
-            }
+        const int totz = (m - h) * C;
+        for (int e = tid; e < totz; e += kThreads) {
+            const int u = h + (e >> shift), cc = e & (C - 1);
+            if (cc < lines) buf[cc * pitch + phys(u)] = make_float2(0.0f, 0.0f);
         }
     }
+    lds_barrier();
+    fft_lines(buf, lines, pitch, a.pl, twl);
+    for_slots(total,
+              [&](int e) {
+                  Slot v;
+                  if (blu) v.c = a.pl.chirp[e >> shift];
+                  return v;
+              },
+              [&](int e, const Slot &v) {
+                  const int u = e >> shift, cc = e & (C - 1);
+                  if (cc < lines) {
+                      const float2 z = store_value<INV>(buf[cc * pitch + phys(u)], v.c, blu);
+                      plane[(size_t)u * a.ld + cc] = make_float2(z.x * a.scale, z.y * a.scale);
+                  }
+              });
 }
 
 template <typename K>
@@ -201,6 +171,7 @@ int make_plan(int n, Plan1D *out, void (*own)(void *ctx, void *dev), void *ctx) 
     pl.n = n;
     pl.bluestein = factor_smooth(n, pl.radix, &pl.nstages) ? 0 : 1;
     pl.m = pl.bluestein ? bluestein_length(n) : n;
+    pl.tw_len = twiddle_entries(pl.m);
     if (pl.m > kMaxElems) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d needs %d LDS elements (max %d)", n, pl.m, kMaxElems);
     if (pl.bluestein && !factor_smooth(pl.m, pl.radix, &pl.nstages)) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d", n);
     auto upload = [&](const std::vector<cd> &v, const float2 **dev) -> int {
@@ -245,13 +216,13 @@ int rows_per_group(const Plan1D &pl, long long total_rows) {
 }
 int cols_per_group(const Plan1D &pl, int cols) {
     int c = 1;
-    while (c < cols && c * 2 <= 32 && c * 2 * pl.m <= max_elems(pl) && c * 2 * col_pitch(pl, c * 2) <= kLdsElems) c *= 2;
+    while (c < cols && c * 2 <= 32 && c * 2 * pl.m <= max_elems(pl) && c * 2 * col_pitch(pl, c * 2) + pl.tw_len <= kLdsElems) c *= 2;
     return c;
 }
 
 int launch_rows(const RowArgs &a, RowLoad load, RowStore store, bool inverse, hipStream_t s) {
     const dim3 grid((unsigned)((a.rows + a.lines - 1) / a.lines));
-    const size_t lds = (size_t)a.lines * row_pitch(a.pl) * sizeof(float2);
+    const size_t lds = row_lds_bytes(a.pl, a.lines);
     if (load == kLoadComplex && store == kStoreComplex) launch_rows_dir<kLoadComplex, kStoreComplex>(a, inverse, grid, lds, s);
     else if (load == kLoadReal && store == kStoreComplex) launch_rows_dir<kLoadReal, kStoreComplex>(a, inverse, grid, lds, s);
     else if (load == kLoadReal && store == kStoreHalf) launch_rows_dir<kLoadReal, kStoreHalf>(a, inverse, grid, lds, s);
@@ -263,7 +234,7 @@ int launch_rows(const RowArgs &a, RowLoad load, RowStore store, bool inverse, hi
 
 int launch_cols(const ColArgs &a, bool inverse, hipStream_t s) {
     const dim3 grid((unsigned)vfi::ceil_div(a.cols, a.tile), (unsigned)a.planes);
-    const size_t lds = (size_t)a.tile * col_pitch(a.pl, a.tile) * sizeof(float2);
+    const size_t lds = col_lds_bytes(a.pl, a.tile);
     allow_lds(fft_cols_kernel<true>);
     allow_lds(fft_cols_kernel<false>);
     if (inverse) hipLaunchKernelGGL(fft_cols_kernel<true>, grid, dim3(kThreads), lds, s, a);

@@ -377,6 +377,387 @@ __global__ void pyr_gain_kernel(float2 *__restrict__ half, const float *__restri
     }
 }
 
+// =====================================================================================================================
+// Fused level kernels on the LDS FFT engine (vfi_fft.h): the band spectra and the band coefficients never exist in HBM.
+//   analysis  level k :  cols kernel : (tile of columns, image): running low-pass spectrum -> for each band
+//                                      i * z * P_a[b] -> inverse column FFT -> T[n][b]   (+ the next level's low-pass;
+//                                      level 0 also expands the R2C half spectrum and emits the high-pass half spectrum)
+//                        rows kernel : rows of T -> inverse row FFT -> 1/(hw) -> atan2 / hypot -> the caller's planes
+//   synthesis level k :  rows kernel : (phase, amplitude) rows -> A cos p, A sin p -> forward row FFT -> T
+//                        cols kernel : (tile, image): sum_b (-i) * FFTcol(T[n][b]) * P_s[b] + embedded coarser level
+// One intermediate (T: 8 bytes per coefficient written and read once) instead of the five full passes of the op-by-op
+// form (band spectrum, 2 x 2 FFT passes, polar).
+// =====================================================================================================================
+using vfi::fft::Plan1D;
+using vfi::fft::kThreads;
+using vfi::fft::mul24;
+
+struct LevelColsArgs {
+    Plan1D ph;                    // column transform (length h)
+    const float2 *src;            // FIRST: R2C half spectrum N x H x (W/2+1); else running low-pass N x h x w
+    float2 *T;                    // N x NB x h x w
+    float2 *next;                 // N x h2 x w2 (may be null when nothing is below)
+    float2 *hi_half;              // FIRST only
+    const float *P, *lomask, *lo0, *hi0;
+    int h, w, h2, w2, tile;
+    float inv_hw;                 // FIRST: 1 / (H W) folded into the high-pass half spectrum
+};
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (own L2).  A column tile is only tile*8 bytes wide, so the tiles
+// that share 128-byte lines are dealt to the SAME XCD back to back.
+__device__ __forceinline__ int tile_of_block(int b, int ntiles) {
+    const int per = (ntiles + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+template <bool FIRST, int NB>
+__global__ __launch_bounds__(kThreads, 2) void pyr_level_cols_kernel(const LevelColsArgs a) {
+    using namespace vfi::fft;
+    extern __shared__ float2 buf[];
+    const int h = a.h, w = a.w, m = a.ph.m, tid = threadIdx.x, C = a.tile, n = blockIdx.y;
+    const int ntiles = (w + C - 1) / C;
+    const int tile = tile_of_block(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);
+    const int v0 = tile * C, lines = w - v0 < C ? w - v0 : C;
+    const int shift = __ffs(C) - 1, total = h * C, wh = w / 2 + 1;
+    const bool blu = a.ph.bluestein != 0;
+    const size_t hw = (size_t)h * w;
+    const float2 *srcn = a.src + (FIRST ? (size_t)n * h * wh : (size_t)n * hw);      // (32-bit offsets inside a plane)
+    auto load_z = [&](int u, int v) -> float2 {          // this level's low-pass spectrum at (u, v)
+        if (FIRST) {
+            float2 z;
+            if (v < wh) z = srcn[mul24(u, wh) + v];
+            else { z = srcn[mul24(u ? h - u : 0, wh) + (w - v)]; z.y = -z.y; }
+            const float l0 = a.lo0[mul24(u, w) + v];
+            return make_float2(z.x * l0, z.y * l0);
+        }
+        return srcn[mul24(u, w) + v];
+    };
+    // -- the next level's low-pass spectrum (crop + lomask) and, at level 0, the high-pass half spectrum ------------
+    if (a.next) {
+        const int h2 = a.h2, w2 = a.w2;
+        float2 *nextn = a.next + (size_t)n * h2 * w2;
+        auto window = [&](int e, int &o2) -> bool {       // is element e inside the next level's window? -> its offset there
+            const int u = e >> shift, cc = e & (C - 1), v = v0 + cc;
+            if (cc >= lines) return false;
+            const int fy = signed_freq(u, h), fx = signed_freq(v, w);
+            if (!(fy >= -(h2 / 2) && fy <= h2 - h2 / 2 - 1 && fx >= -(w2 / 2) && fx <= w2 - w2 / 2 - 1)) return false;
+            o2 = mul24(fy < 0 ? fy + h2 : fy, w2) + (fx < 0 ? fx + w2 : fx);
+            return true;
+        };
+        for_slots(total,
+                  [&](int e) {
+                      Slot s;
+                      int o2 = 0;
+                      s.z = make_float2(0.0f, 0.0f);
+                      s.s = 0.0f;
+                      if (window(e, o2)) {
+                          s.z = load_z(e >> shift, v0 + (e & (C - 1)));
+                          s.s = a.lomask[o2];
+                      }
+                      return s;
+                  },
+                  [&](int e, const Slot &s) {
+                      int o2 = 0;
+                      if (window(e, o2)) nextn[o2] = make_float2(s.z.x * s.s, s.z.y * s.s);
+                  });
+    }
+    if (FIRST && a.hi_half) {
+        float2 *hin = a.hi_half + (size_t)n * h * wh;
+        for_slots(total,
+                  [&](int e) {
+                      const int u = e >> shift, cc = e & (C - 1), v = v0 + cc;
+                      Slot s;
+                      s.z = make_float2(0.0f, 0.0f);
+                      s.s = 0.0f;
+                      if (cc < lines && v < wh) {
+                          s.z = srcn[mul24(u, wh) + v];
+                          s.s = a.hi0[mul24(u, w) + v] * a.inv_hw;
+                      }
+                      return s;
+                  },
+                  [&](int e, const Slot &s) {
+                      const int u = e >> shift, cc = e & (C - 1), v = v0 + cc;
+                      if (cc < lines && v < wh) hin[mul24(u, wh) + v] = make_float2(s.z.x * s.s, s.z.y * s.s);
+                  });
+    }
+    if (!a.T) return;
+    float2 *twl = buf + (size_t)C * pitch;
+    load_twiddles(twl, a.ph);
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+        // fill: conj(i * z * P_a[b]) (* chirp): the inverse transform runs as a forward one on conjugated data.  The tile
+        // of z is re-read per band (L2) rather than kept in 70 registers across the stage calls.
+        const float *Pb = a.P + (size_t)b * hw;
+        for_slots(total,
+                  [&](int e) {
+                      const int u = e >> shift, cc = e & (C - 1), v = v0 + (cc < lines ? cc : 0);
+                      Slot s;
+                      s.z = load_z(u, v);
+                      s.s = Pb[mul24(u, w) + v];
+                      if (blu) s.c = a.ph.chirp[u];
+                      return s;
+                  },
+                  [&](int e, const Slot &s) {
+                      const int u = e >> shift, cc = e & (C - 1);
+                      if (cc < lines)      // * i : (re, im) -> (-im, re)
+                          buf[mul24(cc, pitch) + phys(u)] = load_value<true>(make_float2(-(s.z.y * s.s), s.z.x * s.s), s.c, blu);
+                  });
+        if (blu) {
+            const int totz = (m - h) * C;
+            for (int e = tid; e < totz; e += kThreads) {
+                const int u = h + (e >> shift), cc = e & (C - 1);
+                if (cc < lines) buf[cc * pitch + phys(u)] = make_float2(0.0f, 0.0f);
+            }
+        }
+        lds_barrier();
+        fft_lines(buf, lines, pitch, a.ph, twl);
+        float2 *Tb = a.T + ((size_t)n * NB + b) * hw + v0;
+        for_slots(total,
+                  [&](int e) {
+                      Slot s;
+                      if (blu) s.c = a.ph.chirp[e >> shift];
+                      return s;
+                  },
+                  [&](int e, const Slot &s) {
+                      const int u = e >> shift, cc = e & (C - 1);
+                      if (cc < lines) Tb[mul24(u, w) + cc] = store_value<true>(buf[mul24(cc, pitch) + phys(u)], s.c, blu);
+                  });
+        lds_barrier();
+    }
+}
+
+struct RowsPolarArgs {
+    Plan1D pw;                    // row transform (length w)
+    float2 *T;                    // planes x h x w
+    float *phase, *amp;           // caller's planes (PlaneMap)
+    PlaneMap pm;
+    long long rows;               // planes * h
+    int h, lines;
+    float inv_hw, phase_scale;
+};
+
+// per-line output base (in elements of h*w planes): plane map applied once per row, not per element
+__device__ __forceinline__ void line_bases(size_t *base, int lines, long long row0, int h, int w, const PlaneMap &pm, int NB) {
+    for (int l = threadIdx.x; l < lines; l += kThreads) {
+        const long long g = row0 + l;
+        const int plane = (int)(g / h), y = (int)(g - (long long)plane * h), n = plane / NB, b = plane - n * NB;
+        base[l] = (size_t)(pm.idx[n] + b * pm.band_stride) * h * w + (size_t)y * w;
+    }
+}
+
+__device__ __forceinline__ void zero_row_padding(float2 *buf, int lines, int pitch, int w, int m) {
+    using namespace vfi::fft;
+    const int pad = m - w, totz = lines * pad;
+    const float inv_pad = 1.0f / (float)pad;
+    for (int e = threadIdx.x; e < totz; e += kThreads) {
+        const int l = fast_div(e, inv_pad), j = w + e - l * pad;
+        buf[l * pitch + phys(j)] = make_float2(0.0f, 0.0f);
+    }
+}
+
+// rows of T -> inverse row FFT -> (phase, amplitude) or the complex coefficient (coeff_to_values, src/train/pyramid.py:63-69)
+template <int NB>
+__global__ __launch_bounds__(kThreads, 2) void pyr_rows_polar_kernel(const RowsPolarArgs a) {
+    using namespace vfi::fft;
+    extern __shared__ float2 buf[];
+    const int w = a.pw.n, m = a.pw.m, pitch = padded_length(m);
+    const long long row0 = (long long)blockIdx.x * a.lines;
+    const int lines = (int)(a.rows - row0 < a.lines ? a.rows - row0 : a.lines);
+    float2 *twl = buf + (size_t)a.lines * pitch;
+    size_t *base = reinterpret_cast<size_t *>(twl + a.pw.tw_len);
+    load_twiddles(twl, a.pw);
+    line_bases(base, lines, row0, a.h, w, a.pm, NB);
+    const int total = lines * w;
+    const float inv_w = 1.0f / (float)w;
+    const bool blu = a.pw.bluestein != 0;
+    const float2 *Trow = a.T + row0 * w;
+    for_slots(total,
+              [&](int e) {
+                  Slot s;
+                  s.z = Trow[e];
+                  if (blu) s.c = a.pw.chirp[e - mul24(fast_div(e, inv_w), w)];
+                  return s;
+              },
+              [&](int e, const Slot &s) {
+                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
+                  buf[mul24(l, pitch) + phys(j)] = load_value<true>(s.z, s.c, blu);
+              });
+    if (blu) zero_row_padding(buf, lines, pitch, w, m);
+    lds_barrier();
+    fft_lines(buf, lines, pitch, a.pw, twl);
+    for_slots(total,
+              [&](int e) {
+                  Slot s;
+                  if (blu) s.c = a.pw.chirp[e - mul24(fast_div(e, inv_w), w)];
+                  return s;
+              },
+              [&](int e, const Slot &s) {
+                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
+                  const float2 z = store_value<true>(buf[mul24(l, pitch) + phys(j)], s.c, blu);
+                  const float re = z.x * a.inv_hw, im = z.y * a.inv_hw;
+                  const size_t o = base[l] + j;
+                  if (a.pm.complex_coeff) {
+                      reinterpret_cast<float2 *>(a.phase)[o] = make_float2(re, im);
+                  } else {
+                      a.phase[o] = atan2f(im, re) * a.phase_scale;
+                      a.amp[o] = sqrtf(re * re + im * im);
+                  }
+              });
+}
+
+// (phase, amplitude) rows -> complex -> forward row FFT -> T (values_to_coeff, src/train/pyramid.py:99-107, + the row half of
+// reconstruct's fft2)
+template <int NB>
+__global__ __launch_bounds__(kThreads, 2) void pyr_rows_from_polar_kernel(const RowsPolarArgs a) {
+    using namespace vfi::fft;
+    extern __shared__ float2 buf[];
+    const int w = a.pw.n, m = a.pw.m, pitch = padded_length(m);
+    const long long row0 = (long long)blockIdx.x * a.lines;
+    const int lines = (int)(a.rows - row0 < a.lines ? a.rows - row0 : a.lines);
+    float2 *twl = buf + (size_t)a.lines * pitch;
+    size_t *base = reinterpret_cast<size_t *>(twl + a.pw.tw_len);
+    load_twiddles(twl, a.pw);
+    line_bases(base, lines, row0, a.h, w, a.pm, NB);
+    lds_barrier();
+    const int total = lines * w;
+    const float inv_w = 1.0f / (float)w;
+    const bool blu = a.pw.bluestein != 0;
+    for_slots(total,
+              [&](int e) {
+                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
+                  const size_t o = base[l] + j;
+                  Slot s;
+                  if (a.pm.complex_coeff) s.z = reinterpret_cast<const float2 *>(a.phase)[o];
+                  else s.z = make_float2(a.phase[o], a.amp[o]);
+                  if (blu) s.c = a.pw.chirp[j];
+                  return s;
+              },
+              [&](int e, const Slot &s) {
+                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
+                  float2 x = s.z;
+                  if (!a.pm.complex_coeff) {
+                      float sn, cs;
+                      sincosf(s.z.x, &sn, &cs);
+                      x = make_float2(cs * s.z.y, sn * s.z.y);
+                  }
+                  buf[mul24(l, pitch) + phys(j)] = load_value<false>(x, s.c, blu);
+              });
+    if (blu) zero_row_padding(buf, lines, pitch, w, m);
+    lds_barrier();
+    fft_lines(buf, lines, pitch, a.pw, twl);
+    float2 *Trow = a.T + row0 * w;
+    for_slots(total,
+              [&](int e) {
+                  Slot s;
+                  if (blu) s.c = a.pw.chirp[e - mul24(fast_div(e, inv_w), w)];
+                  return s;
+              },
+              [&](int e, const Slot &s) {
+                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
+                  Trow[e] = store_value<false>(buf[mul24(l, pitch) + phys(j)], s.c, blu);
+              });
+}
+
+struct CombineColsArgs {
+    Plan1D ph;
+    const float2 *T;              // N x NB x h x w (row-transformed bands)
+    const float2 *res;            // N x h2 x w2 (coarser level's spectrum; may be null)
+    float2 *cur;                  // N x h x w
+    const float *P, *lomask;
+    int h, w, h2, w2, tile;
+};
+
+// cur = sum_b (-i) * FFTcol(T_b) * P_s[b]  +  embed(res * lomask)     (reconstruct: orientdft + resdft)
+template <int NB>
+__global__ __launch_bounds__(kThreads, 2) void pyr_combine_cols_kernel(const CombineColsArgs a) {
+    using namespace vfi::fft;
+    extern __shared__ float2 buf[];
+    const int h = a.h, w = a.w, m = a.ph.m, tid = threadIdx.x, C = a.tile, n = blockIdx.y;
+    const int ntiles = (w + C - 1) / C;
+    const int tile = tile_of_block(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);
+    const int v0 = tile * C, lines = w - v0 < C ? w - v0 : C;
+    const int shift = __ffs(C) - 1, total = h * C;
+    const bool blu = a.ph.bluestein != 0;
+    const size_t hw = (size_t)h * w;
+    float2 *cur = a.cur + (size_t)n * hw + v0;
+    float2 *twl = buf + (size_t)C * pitch;
+    load_twiddles(twl, a.ph);
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+        const float2 *Tb = a.T + ((size_t)n * NB + b) * hw + v0;
+        const float *Pb = a.P + (size_t)b * hw;
+        for_slots(total,
+                  [&](int e) {
+                      const int u = e >> shift, cc = e & (C - 1);
+                      Slot s;
+                      s.z = Tb[mul24(u, w) + (cc < lines ? cc : 0)];
+                      if (blu) s.c = a.ph.chirp[u];
+                      return s;
+                  },
+                  [&](int e, const Slot &s) {
+                      const int u = e >> shift, cc = e & (C - 1);
+                      if (cc < lines) buf[mul24(cc, pitch) + phys(u)] = load_value<false>(s.z, s.c, blu);
+                  });
+        if (blu) {
+            const int totz = (m - h) * C;
+            for (int e = tid; e < totz; e += kThreads) {
+                const int u = h + (e >> shift), cc = e & (C - 1);
+                if (cc < lines) buf[cc * pitch + phys(u)] = make_float2(0.0f, 0.0f);
+            }
+        }
+        lds_barrier();
+        fft_lines(buf, lines, pitch, a.ph, twl);
+        // drain: band 0 starts the sum from the embedded coarser level, bands 1.. add to what this thread wrote for the
+        // previous band (its own elements: still in L2)
+        for_slots(total,
+                  [&](int e) {
+                      const int u = e >> shift, cc = e & (C - 1), v = v0 + (cc < lines ? cc : 0);
+                      Slot s;
+                      if (blu) s.c = a.ph.chirp[u];
+                      s.s = Pb[mul24(u, w) + v];
+                      if (b == 0) {
+                          s.z = make_float2(0.0f, 0.0f);
+                          if (a.res) {
+                              const int h2 = a.h2, w2 = a.w2, fy = signed_freq(u, h), fx = signed_freq(v, w);
+                              if (fy >= -(h2 / 2) && fy <= h2 - h2 / 2 - 1 && fx >= -(w2 / 2) && fx <= w2 - w2 / 2 - 1) {
+                                  const int u2 = fy < 0 ? fy + h2 : fy, v2 = fx < 0 ? fx + w2 : fx;
+                                  const float2 r = a.res[((size_t)n * h2 + u2) * w2 + v2];
+                                  const float lom = a.lomask[(size_t)u2 * w2 + v2];
+                                  s.z = make_float2(r.x * lom, r.y * lom);
+                              }
+                          }
+                      } else {
+                          s.z = cur[mul24(u, w) + (cc < lines ? cc : 0)];
+                      }
+                      return s;
+                  },
+                  [&](int e, const Slot &s) {
+                      const int u = e >> shift, cc = e & (C - 1);
+                      if (cc < lines) {
+                          const float2 z = store_value<false>(buf[mul24(cc, pitch) + phys(u)], s.c, blu);
+                          // * (-i) : (re, im) -> (im, -re)
+                          cur[mul24(u, w) + cc] = make_float2(s.z.x + z.y * s.s, s.z.y - z.x * s.s);
+                      }
+                  });
+        lds_barrier();
+    }
+}
+
+template <typename K>
+void allow_big_lds(K kernel) {      // > 64 KiB of dynamic LDS needs the attribute, per device (idempotent)
+    static bool done[vfi::kMaxDevices] = {};
+    bool &d = done[vfi::current_device()];
+    if (!d) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(vfi::fft::kLdsElems * sizeof(float2) + 8192));
+        d = true;
+    }
+}
+
 // ---- 2-D transforms = a row pass and a column pass of the LDS engine (vfi_fft.h / vfi_fft.hip) ---------------------------
 int get_fft(vfi_pyr_plan *p, int n, vfi::fft::Plan1D *out) {
     auto it = p->fft1d.find(n);
@@ -567,20 +948,41 @@ extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *
         const int wb = (level_mask >> k) & 1ull ? 1 : 0;
         if (wb) VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
                             "vfi_pyr_analyze: null output for level %d", k);
-        dim3 grid(ceil_div(L.w, 256), L.h);
-        if (k == 0)
-            hipLaunchKernelGGL((pyr_analysis_level_kernel<true, 4>), grid, dim3(256), 0, s, src, p->bands, next, p->half_hi,
-                               L.P_a, L.lomask, p->lo0, p->hi0, N, L.h, L.w, h2, w2, wb, 1.0f / ((float)H * (float)W));
-        else
-            hipLaunchKernelGGL((pyr_analysis_level_kernel<false, 4>), grid, dim3(256), 0, s, src, p->bands, next, nullptr,
-                               L.P_a, L.lomask, nullptr, nullptr, N, L.h, L.w, h2, w2, wb, 0.0f);
-        if (wb) {
-            if ((rc = fft2d_c2c(p, p->bands, N * nb, L.h, L.w, true, s))) return rc;
-            const int hw = L.h * L.w;
-            hipLaunchKernelGGL((pyr_polar_kernel<4>), dim3(ceil_div(hw, 256), N * nb), dim3(256), 0, s, p->bands, phase[k],
-                               amp ? amp[k] : nullptr, make_map(plane_index, k, N, nb, flags), N, hw, 1.0f / (float)hw,
-                               phase_scale);
+        const bool need_next = (level_mask >> (k + 1)) != 0 || low != nullptr;     // anything below this level?
+        if (!wb) {      // level not wanted: only pass the low-pass spectrum down (and emit the high-pass half spectrum)
+            if (!need_next && !(k == 0 && high)) { src = next; continue; }
+            dim3 grid(ceil_div(L.w, 256), L.h);
+            if (k == 0)
+                hipLaunchKernelGGL((pyr_analysis_level_kernel<true, 4>), grid, dim3(256), 0, s, src, p->bands, next, p->half_hi,
+                                   L.P_a, L.lomask, p->lo0, p->hi0, N, L.h, L.w, h2, w2, 0, 1.0f / ((float)H * (float)W));
+            else
+                hipLaunchKernelGGL((pyr_analysis_level_kernel<false, 4>), grid, dim3(256), 0, s, src, p->bands, next, nullptr,
+                                   L.P_a, L.lomask, nullptr, nullptr, N, L.h, L.w, h2, w2, 0, 0.0f);
+            src = next;
+            continue;
         }
+        using namespace vfi::fft;
+        Plan1D ph, pw;
+        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw))) return rc;
+        LevelColsArgs ca{ph, src, p->bands, need_next ? next : nullptr, k == 0 && high ? p->half_hi : nullptr, L.P_a, L.lomask,
+                         p->lo0, p->hi0, L.h, L.w, h2, w2, cols_per_group(ph, L.w), 1.0f / ((float)H * (float)W)};
+        const dim3 cgrid(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N);
+        const size_t clds = col_lds_bytes(ph, ca.tile);
+        if (k == 0) {
+            allow_big_lds(pyr_level_cols_kernel<true, 4>);
+            hipLaunchKernelGGL((pyr_level_cols_kernel<true, 4>), cgrid, dim3(kThreads), clds, s, ca);
+        } else {
+            allow_big_lds(pyr_level_cols_kernel<false, 4>);
+            hipLaunchKernelGGL((pyr_level_cols_kernel<false, 4>), cgrid, dim3(kThreads), clds, s, ca);
+        }
+        const long long rows = (long long)N * nb * L.h;
+        int lines = rows_per_group(pw, rows);
+        if (lines > 256) lines = 256;
+        RowsPolarArgs ra{pw, p->bands, phase[k], amp ? amp[k] : nullptr, make_map(plane_index, k, N, nb, flags), rows, L.h, lines,
+                         1.0f / ((float)L.h * (float)L.w), phase_scale};
+        allow_big_lds(pyr_rows_polar_kernel<4>);
+        hipLaunchKernelGGL((pyr_rows_polar_kernel<4>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                           row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
         src = next;
     }
     if (low) {  // low residual: real(ifft2(lodft))
@@ -617,17 +1019,30 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
         const Level &L = p->lev[k];
         const int h2 = k + 1 < p->nlev ? p->lev[k + 1].h : p->hl, w2 = k + 1 < p->nlev ? p->lev[k + 1].w : p->wl;
         const int hb = (level_mask >> k) & 1ull ? 1 : 0;
-        const int hw = L.h * L.w;
-        if (hb) {
-            VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
-                        "vfi_pyr_synthesize: null input for level %d", k);
-            hipLaunchKernelGGL((pyr_to_complex_kernel<4>), dim3(ceil_div(hw, 256), N * nb), dim3(256), 0, s, phase[k],
-                               amp ? amp[k] : nullptr, p->bands, make_map(plane_index, k, N, nb, flags), N, hw);
-            if ((rc = fft2d_c2c(p, p->bands, N * nb, L.h, L.w, false, s))) return rc;
-        }
         float2 *cur = p->lod[k & 1];
-        hipLaunchKernelGGL((pyr_combine_kernel<4>), dim3(ceil_div(L.w, 256), L.h), dim3(256), 0, s, p->bands, res, cur, L.P_s,
-                           L.lomask, N, L.h, L.w, h2, w2, hb);
+        if (!hb) {      // no bands at this level: embed the coarser spectrum only
+            hipLaunchKernelGGL((pyr_combine_kernel<4>), dim3(ceil_div(L.w, 256), L.h), dim3(256), 0, s, p->bands, res, cur, L.P_s,
+                               L.lomask, N, L.h, L.w, h2, w2, 0);
+            res = cur;
+            continue;
+        }
+        VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
+                    "vfi_pyr_synthesize: null input for level %d", k);
+        using namespace vfi::fft;
+        Plan1D ph, pw;
+        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw))) return rc;
+        const long long rows = (long long)N * nb * L.h;
+        int lines = rows_per_group(pw, rows);
+        if (lines > 256) lines = 256;
+        RowsPolarArgs ra{pw, p->bands, const_cast<float *>(phase[k]), amp ? const_cast<float *>(amp[k]) : nullptr,
+                         make_map(plane_index, k, N, nb, flags), rows, L.h, lines, 1.0f, 1.0f};
+        allow_big_lds(pyr_rows_from_polar_kernel<4>);
+        hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                           row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        CombineColsArgs ca{ph, p->bands, res, cur, L.P_s, L.lomask, L.h, L.w, h2, w2, cols_per_group(ph, L.w)};
+        allow_big_lds(pyr_combine_cols_kernel<4>);
+        hipLaunchKernelGGL((pyr_combine_cols_kernel<4>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
+                           col_lds_bytes(ph, ca.tile), s, ca);
         res = cur;
     }
     const float2 *hi_half = nullptr;

@@ -22,6 +22,7 @@ static void build(HostPlan &hp, int n) {
     pl.n = n;
     pl.bluestein = !factor_smooth(n, pl.radix, &pl.nstages);
     pl.m = pl.bluestein ? bluestein_length(n) : n;
+    pl.tw_len = twiddle_entries(pl.m);
     if (pl.bluestein && !factor_smooth(pl.m, pl.radix, &pl.nstages)) { std::printf("plan failed for %d\n", n); std::exit(2); }
     hp.tw.resize(pl.m);
     for (int k = 0; k < pl.m; ++k) hp.tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / pl.m), (float)std::sin(-2.0 * M_PI * k / pl.m));
@@ -47,30 +48,32 @@ static void build(HostPlan &hp, int n) {
 }
 
 template <int R, bool MULB>
-static void host_stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, const float2 *bfilt) {
+static void host_stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, int tw_len, const float2 *bfilt) {
     std::vector<StageRegs<R>> regs(kThreads);
-    for (int t = 0; t < kThreads; ++t) stage_gather<R, MULB>(regs[t], t, buf, lines, pitch, m, p, tw, bfilt);
+    for (int t = 0; t < kThreads; ++t) stage_gather<R, MULB>(regs[t], t, buf, lines, pitch, m, p, tw, tw_len, bfilt);
     for (int t = 0; t < kThreads; ++t) stage_scatter<R>(regs[t], t, buf, lines, pitch, m, p);
 }
 template <bool MULB>
-static void host_stage_any(int R, float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, const float2 *bfilt) {
+static void host_stage_any(int R, float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, int tw_len, const float2 *bfilt) {
     switch (R) {
-        case 16: host_stage<16, MULB>(buf, lines, pitch, m, p, tw, bfilt); break;
-        case 8: host_stage<8, MULB>(buf, lines, pitch, m, p, tw, bfilt); break;
-        case 4: host_stage<4, MULB>(buf, lines, pitch, m, p, tw, bfilt); break;
-        case 2: host_stage<2, MULB>(buf, lines, pitch, m, p, tw, bfilt); break;
-        case 3: host_stage<3, MULB>(buf, lines, pitch, m, p, tw, bfilt); break;
-        default: host_stage<5, MULB>(buf, lines, pitch, m, p, tw, bfilt); break;
+        case 16: host_stage<16, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt); break;
+        case 15: host_stage<15, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt); break;
+        case 9: host_stage<9, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt); break;
+        case 8: host_stage<8, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt); break;
+        case 4: host_stage<4, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt); break;
+        case 2: host_stage<2, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt); break;
+        case 3: host_stage<3, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt); break;
+        default: host_stage<5, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt); break;
     }
 }
 // mirrors fft_lines of vfi_fft.h
 static void host_fft(float2 *buf, int lines, int pitch, const Plan1D &pl) {
     int p = 1;
-    for (int s = 0; s < pl.nstages; ++s) { host_stage_any<false>(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw, nullptr); p *= pl.radix[s]; }
+    for (int s = 0; s < pl.nstages; ++s) { host_stage_any<false>(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw, pl.tw_len, nullptr); p *= pl.radix[s]; }
     if (!pl.bluestein) return;
-    host_stage_any<true>(pl.radix[0], buf, lines, pitch, pl.m, 1, pl.tw, pl.bfilt);
+    host_stage_any<true>(pl.radix[0], buf, lines, pitch, pl.m, 1, pl.tw, pl.tw_len, pl.bfilt);
     p = pl.radix[0];
-    for (int s = 1; s < pl.nstages; ++s) { host_stage_any<false>(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw, nullptr); p *= pl.radix[s]; }
+    for (int s = 1; s < pl.nstages; ++s) { host_stage_any<false>(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw, pl.tw_len, nullptr); p *= pl.radix[s]; }
 }
 
 static double check(int n, int lines, bool inv) {
