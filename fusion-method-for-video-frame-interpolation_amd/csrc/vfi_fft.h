@@ -340,6 +340,63 @@ __device__ __forceinline__ void for_slots(int total, LoadF load, UseF use) {
     }
 }
 
+// ---- structured slot walks: almost no per-element index arithmetic ---------------------------------------------------
+// Column tile (C = 1 << shift columns, h rows; line = column): thread t owns column cc = t & (C-1) and the rows
+// u = u0 + step*q (u0 = t >> shift, step = 256 >> shift).  The LDS index of (cc, u) is cc*pitch + phys(u) and
+// phys(u0 + step*q) = phys(u0) + step*q + ((step*q) >> 5) exactly (the low five bits of step*q and u0 never carry), so it is
+// a per-thread base plus a UNIFORM term; global offsets are a per-thread base plus uq * row_pitch (uniform) as well.
+//   load(u, uq, cc) -> Slot          (uq = step*q, uniform; u = u0 + uq)
+//   use(u, uq, cc, lds_index, slot)
+template <typename LoadF, typename UseF>
+__device__ __forceinline__ void for_tile(int h, int shift, int pitch, LoadF load, UseF use) {
+    const int t = threadIdx.x, cc = t & ((1 << shift) - 1), u0 = t >> shift, step = kThreads >> shift;
+    const int lbase = mul24(cc, pitch) + phys(u0);
+    const int nq = (h - 1) / step + 1;                            // (uniform) slots per thread
+    for (int q0 = 0; q0 < nq; q0 += kChunk) {
+        Slot v[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (q0 + q < nq) {
+                const int uq = step * (q0 + q), u = u0 + uq;
+                v[q] = load(u < h ? u : u0, u < h ? uq : 0, cc);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (q0 + q < nq) {
+                const int uq = step * (q0 + q), u = u0 + uq;
+                if (u < h) use(u, uq, cc, lbase + uq + (uq >> 5), v[q]);
+            }
+        }
+    }
+}
+// Rows (`lines` rows of n >= 256 elements; line = row): thread t owns the columns j = t + 256*qq of every row.
+// phys(t + 256*qq) = phys(t) + 264*qq, so the LDS index is phys(t) + (l*pitch + 264*qq), the bracket uniform.
+//   load(l, j, jq) -> Slot           (jq = 256*qq uniform; j = t + jq)
+//   use(l, j, jq, lds_index, slot)
+template <typename LoadF, typename UseF>
+__device__ __forceinline__ void for_rows(int lines, int n, int pitch, LoadF load, UseF use) {
+    const int t = threadIdx.x, pt = phys(t);
+    const int qn = (n - 1) / kThreads + 1, ns = lines * qn;       // (uniform)
+    for (int s0 = 0; s0 < ns; s0 += kChunk) {
+        Slot v[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (s0 + q < ns) {
+                const int l = (s0 + q) / qn, qq = (s0 + q) - l * qn, jq = kThreads * qq, j = t + jq;
+                v[q] = load(l, j < n ? j : 0, j < n ? jq : -t);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (s0 + q < ns) {
+                const int l = (s0 + q) / qn, qq = (s0 + q) - l * qn, jq = kThreads * qq, j = t + jq;
+                if (j < n) use(l, j, jq, pt + (l * pitch + 264 * qq), v[q]);
+            }
+        }
+    }
+}
+
 // ---- device entry: all 256 threads of the workgroup call it; the lines must be filled and synchronised -----------------
 // Stages are real function calls (one body per radix, shared by every kernel and every position in the stage list):
 // inlined, the ~10 unrolled bodies of a kernel made the register allocator spill kilobytes per lane.

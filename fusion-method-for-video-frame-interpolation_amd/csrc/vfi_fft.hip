@@ -52,25 +52,27 @@ __global__ __launch_bounds__(kThreads, 2) void fft_rows_kernel(const RowArgs a) 
     const bool blu = a.pl.bluestein != 0;
     float2 *twl = buf + (size_t)a.lines * pitch;
     load_twiddles(twl, a.pl);
-    for_slots(lines * n,
-              [&](int e) {
-                  const int l = fast_div(e, inv_n), j = e - l * n;
-                  Slot v;
-                  if (LOAD == kLoadComplex) {
-                      v.z = static_cast<const float2 *>(a.src)[(row0 + l) * a.src_pitch + j];
-                  } else if (LOAD == kLoadReal) {
-                      v.z = make_float2(static_cast<const float *>(a.src)[(row0 + l) * a.src_pitch + j], 0.0f);
-                  } else {
-                      const float2 *r = static_cast<const float2 *>(a.src) + (row0 + l) * a.src_pitch;
-                      v.z = j < wh ? r[j] : cconj(r[n - j]);
-                  }
-                  if (blu) v.c = a.pl.chirp[j];
-                  return v;
-              },
-              [&](int e, const Slot &v) {
-                  const int l = fast_div(e, inv_n), j = e - l * n;
-                  buf[l * pitch + phys(j)] = load_value<INV>(v.z, v.c, blu);
-              });
+    auto fill_load = [&](int l, int j) {
+        Slot v;
+        if (LOAD == kLoadComplex) {
+            v.z = (static_cast<const float2 *>(a.src) + (row0 + l) * a.src_pitch)[j];
+        } else if (LOAD == kLoadReal) {
+            v.z = make_float2((static_cast<const float *>(a.src) + (row0 + l) * a.src_pitch)[j], 0.0f);
+        } else {
+            const float2 *r = static_cast<const float2 *>(a.src) + (row0 + l) * a.src_pitch;
+            v.z = j < wh ? r[j] : cconj(r[n - j]);
+        }
+        if (blu) v.c = a.pl.chirp[j];
+        return v;
+    };
+    auto fill_use = [&](int idx, const Slot &v) { buf[idx] = load_value<INV>(v.z, v.c, blu); };
+    const bool wide = n >= kThreads;
+    if (wide)
+        for_rows(lines, n, pitch, [&](int l, int j, int) { return fill_load(l, j); },
+                 [&](int, int, int, int idx, const Slot &v) { fill_use(idx, v); });
+    else
+        for_slots(lines * n, [&](int e) { const int l = fast_div(e, inv_n); return fill_load(l, e - mul24(l, n)); },
+                  [&](int e, const Slot &v) { const int l = fast_div(e, inv_n); fill_use(mul24(l, pitch) + phys(e - mul24(l, n)), v); });
     if (blu) {                                     // zero padding [n, m)
         const int pad = m - n, totz = lines * pad;
         const float inv_pad = 1.0f / (float)pad;
@@ -83,18 +85,25 @@ __global__ __launch_bounds__(kThreads, 2) void fft_rows_kernel(const RowArgs a) 
     fft_lines(buf, lines, pitch, a.pl, twl);
     const int nout = STORE == kStoreHalf ? wh : n;
     const float inv_o = 1.0f / (float)nout;
-    for_slots(lines * nout,
-              [&](int e) {
-                  Slot v;
-                  if (blu) v.c = a.pl.chirp[e - fast_div(e, inv_o) * nout];
-                  return v;
-              },
-              [&](int e, const Slot &v) {
-                  const int l = fast_div(e, inv_o), j = e - l * nout;
-                  const float2 z = store_value<INV>(buf[l * pitch + phys(j)], v.c, blu);
-                  if (STORE == kStoreReal) static_cast<float *>(a.dst)[(row0 + l) * a.dst_pitch + j] = z.x * a.scale;
-                  else static_cast<float2 *>(a.dst)[(row0 + l) * a.dst_pitch + j] = make_float2(z.x * a.scale, z.y * a.scale);
-              });
+    auto drain_load = [&](int j) {
+        Slot v;
+        if (blu) v.c = a.pl.chirp[j];
+        return v;
+    };
+    auto drain_use = [&](int l, int j, int idx, const Slot &v) {
+        const float2 z = store_value<INV>(buf[idx], v.c, blu);
+        if (STORE == kStoreReal) (static_cast<float *>(a.dst) + (row0 + l) * a.dst_pitch)[j] = z.x * a.scale;
+        else (static_cast<float2 *>(a.dst) + (row0 + l) * a.dst_pitch)[j] = make_float2(z.x * a.scale, z.y * a.scale);
+    };
+    if (nout >= kThreads)
+        for_rows(lines, nout, pitch, [&](int, int j, int) { return drain_load(j); },
+                 [&](int l, int j, int, int idx, const Slot &v) { drain_use(l, j, idx, v); });
+    else
+        for_slots(lines * nout, [&](int e) { return drain_load(e - mul24(fast_div(e, inv_o), nout)); },
+                  [&](int e, const Slot &v) {
+                      const int l = fast_div(e, inv_o), j = e - mul24(l, nout);
+                      drain_use(l, j, mul24(l, pitch) + phys(j), v);
+                  });
 }
 
 template <bool INV>
@@ -104,23 +113,24 @@ __global__ __launch_bounds__(kThreads, 2) void fft_cols_kernel(const ColArgs a) 
     const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);
     const int v0 = blockIdx.x * C;
     const int lines = a.cols - v0 < C ? a.cols - v0 : C;
-    float2 *plane = a.data + (size_t)blockIdx.y * h * a.ld + v0;
-    const int shift = __ffs(C) - 1, total = h * C;
+    float2 *plane = a.data + (size_t)blockIdx.y * h * a.ld;
+    const int shift = __ffs(C) - 1;
     const bool blu = a.pl.bluestein != 0;
     float2 *twl = buf + (size_t)C * pitch;
     load_twiddles(twl, a.pl);
-    for_slots(total,
-              [&](int e) {
-                  const int u = e >> shift, cc = e & (C - 1);
-                  Slot v;
-                  v.z = plane[(size_t)u * a.ld + (cc < lines ? cc : 0)];
-                  if (blu) v.c = a.pl.chirp[u];
-                  return v;
-              },
-              [&](int e, const Slot &v) {
-                  const int u = e >> shift, cc = e & (C - 1);
-                  if (cc < lines) buf[cc * pitch + phys(u)] = load_value<INV>(v.z, v.c, blu);
-              });
+    const int ccm = tid & (C - 1);
+    const bool ccok = ccm < lines;
+    const int tb = mul24(tid >> shift, a.ld) + v0 + (ccok ? ccm : 0);      // (for_tile: this thread's column)
+    for_tile(h, shift, pitch,
+             [&](int u, int uq, int) {
+                 Slot v;
+                 v.z = plane[tb + mul24(uq, a.ld)];
+                 if (blu) v.c = a.pl.chirp[u];
+                 return v;
+             },
+             [&](int, int, int, int idx, const Slot &v) {
+                 if (ccok) buf[idx] = load_value<INV>(v.z, v.c, blu);
+             });
     if (blu) {
         const int totz = (m - h) * C;
         for (int e = tid; e < totz; e += kThreads) {
@@ -130,19 +140,18 @@ __global__ __launch_bounds__(kThreads, 2) void fft_cols_kernel(const ColArgs a) 
     }
     lds_barrier();
     fft_lines(buf, lines, pitch, a.pl, twl);
-    for_slots(total,
-              [&](int e) {
-                  Slot v;
-                  if (blu) v.c = a.pl.chirp[e >> shift];
-                  return v;
-              },
-              [&](int e, const Slot &v) {
-                  const int u = e >> shift, cc = e & (C - 1);
-                  if (cc < lines) {
-                      const float2 z = store_value<INV>(buf[cc * pitch + phys(u)], v.c, blu);
-                      plane[(size_t)u * a.ld + cc] = make_float2(z.x * a.scale, z.y * a.scale);
-                  }
-              });
+    for_tile(h, shift, pitch,
+             [&](int u, int, int) {
+                 Slot v;
+                 if (blu) v.c = a.pl.chirp[u];
+                 return v;
+             },
+             [&](int, int uq, int, int idx, const Slot &v) {
+                 if (ccok) {
+                     const float2 z = store_value<INV>(buf[idx], v.c, blu);
+                     plane[tb + mul24(uq, a.ld)] = make_float2(z.x * a.scale, z.y * a.scale);
+                 }
+             });
 }
 
 template <typename K>

@@ -485,25 +485,33 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_level_cols_kernel(const Level
     if (!a.T) return;
     float2 *twl = buf + (size_t)C * pitch;
     load_twiddles(twl, a.ph);
+    // this thread's column of the tile (for_tile): validity, a safe column to read, offset of (row u0, that column)
+    const int ccm = tid & (C - 1);
+    const bool ccok = ccm < lines;
+    const int vt = v0 + (ccok ? ccm : 0), tb = mul24(tid >> shift, w) + vt;
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
         // fill: conj(i * z * P_a[b]) (* chirp): the inverse transform runs as a forward one on conjugated data.  The tile
         // of z is re-read per band (L2) rather than kept in 70 registers across the stage calls.
         const float *Pb = a.P + (size_t)b * hw;
-        for_slots(total,
-                  [&](int e) {
-                      const int u = e >> shift, cc = e & (C - 1), v = v0 + (cc < lines ? cc : 0);
-                      Slot s;
-                      s.z = load_z(u, v);
-                      s.s = Pb[mul24(u, w) + v];
-                      if (blu) s.c = a.ph.chirp[u];
-                      return s;
-                  },
-                  [&](int e, const Slot &s) {
-                      const int u = e >> shift, cc = e & (C - 1);
-                      if (cc < lines)      // * i : (re, im) -> (-im, re)
-                          buf[mul24(cc, pitch) + phys(u)] = load_value<true>(make_float2(-(s.z.y * s.s), s.z.x * s.s), s.c, blu);
-                  });
+        for_tile(h, shift, pitch,
+                 [&](int u, int uq, int) {
+                     Slot s;
+                     if (FIRST) {
+                         s.z = load_z(u, vt);
+                         s.s = Pb[mul24(u, w) + vt];
+                     } else {                              // per-thread base + uniform row offset
+                         const int o = tb + mul24(uq, w);
+                         s.z = srcn[o];
+                         s.s = Pb[o];
+                     }
+                     if (blu) s.c = a.ph.chirp[u];
+                     return s;
+                 },
+                 [&](int, int, int, int idx, const Slot &s) {
+                     if (ccok)      // * i : (re, im) -> (-im, re)
+                         buf[idx] = load_value<true>(make_float2(-(s.z.y * s.s), s.z.x * s.s), s.c, blu);
+                 });
         if (blu) {
             const int totz = (m - h) * C;
             for (int e = tid; e < totz; e += kThreads) {
@@ -513,17 +521,16 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_level_cols_kernel(const Level
         }
         lds_barrier();
         fft_lines(buf, lines, pitch, a.ph, twl);
-        float2 *Tb = a.T + ((size_t)n * NB + b) * hw + v0;
-        for_slots(total,
-                  [&](int e) {
-                      Slot s;
-                      if (blu) s.c = a.ph.chirp[e >> shift];
-                      return s;
-                  },
-                  [&](int e, const Slot &s) {
-                      const int u = e >> shift, cc = e & (C - 1);
-                      if (cc < lines) Tb[mul24(u, w) + cc] = store_value<true>(buf[mul24(cc, pitch) + phys(u)], s.c, blu);
-                  });
+        float2 *Tb = a.T + ((size_t)n * NB + b) * hw;
+        for_tile(h, shift, pitch,
+                 [&](int u, int, int) {
+                     Slot s;
+                     if (blu) s.c = a.ph.chirp[u];
+                     return s;
+                 },
+                 [&](int, int uq, int, int idx, const Slot &s) {
+                     if (ccok) Tb[tb + mul24(uq, w)] = store_value<true>(buf[idx], s.c, blu);
+                 });
         lds_barrier();
     }
 }
@@ -573,38 +580,48 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_rows_polar_kernel(const RowsP
     const float inv_w = 1.0f / (float)w;
     const bool blu = a.pw.bluestein != 0;
     const float2 *Trow = a.T + row0 * w;
-    for_slots(total,
-              [&](int e) {
-                  Slot s;
-                  s.z = Trow[e];
-                  if (blu) s.c = a.pw.chirp[e - mul24(fast_div(e, inv_w), w)];
-                  return s;
-              },
-              [&](int e, const Slot &s) {
-                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
-                  buf[mul24(l, pitch) + phys(j)] = load_value<true>(s.z, s.c, blu);
-              });
+    auto fill_load = [&](int l, int j) {
+        Slot s;
+        s.z = Trow[mul24(l, w) + j];
+        if (blu) s.c = a.pw.chirp[j];
+        return s;
+    };
+    auto fill_use = [&](int idx, const Slot &s) { buf[idx] = load_value<true>(s.z, s.c, blu); };
+    auto drain_load = [&](int j) {
+        Slot s;
+        if (blu) s.c = a.pw.chirp[j];
+        return s;
+    };
+    auto drain_use = [&](int l, int j, int idx, const Slot &s) {
+        const float2 z = store_value<true>(buf[idx], s.c, blu);
+        const float re = z.x * a.inv_hw, im = z.y * a.inv_hw;
+        const size_t o = base[l] + j;
+        if (a.pm.complex_coeff) {
+            reinterpret_cast<float2 *>(a.phase)[o] = make_float2(re, im);
+        } else {
+            a.phase[o] = atan2f(im, re) * a.phase_scale;
+            a.amp[o] = sqrtf(re * re + im * im);
+        }
+    };
+    const bool wide = w >= kThreads;          // long rows: the structured walk (no per-element division)
+    if (wide)
+        for_rows(lines, w, pitch, [&](int l, int j, int) { return fill_load(l, j); },
+                 [&](int, int, int, int idx, const Slot &s) { fill_use(idx, s); });
+    else
+        for_slots(total, [&](int e) { const int l = fast_div(e, inv_w); return fill_load(l, e - mul24(l, w)); },
+                  [&](int e, const Slot &s) { const int l = fast_div(e, inv_w); fill_use(mul24(l, pitch) + phys(e - mul24(l, w)), s); });
     if (blu) zero_row_padding(buf, lines, pitch, w, m);
     lds_barrier();
     fft_lines(buf, lines, pitch, a.pw, twl);
-    for_slots(total,
-              [&](int e) {
-                  Slot s;
-                  if (blu) s.c = a.pw.chirp[e - mul24(fast_div(e, inv_w), w)];
-                  return s;
-              },
-              [&](int e, const Slot &s) {
-                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
-                  const float2 z = store_value<true>(buf[mul24(l, pitch) + phys(j)], s.c, blu);
-                  const float re = z.x * a.inv_hw, im = z.y * a.inv_hw;
-                  const size_t o = base[l] + j;
-                  if (a.pm.complex_coeff) {
-                      reinterpret_cast<float2 *>(a.phase)[o] = make_float2(re, im);
-                  } else {
-                      a.phase[o] = atan2f(im, re) * a.phase_scale;
-                      a.amp[o] = sqrtf(re * re + im * im);
-                  }
-              });
+    if (wide)
+        for_rows(lines, w, pitch, [&](int, int j, int) { return drain_load(j); },
+                 [&](int l, int j, int, int idx, const Slot &s) { drain_use(l, j, idx, s); });
+    else
+        for_slots(total, [&](int e) { return drain_load(e - mul24(fast_div(e, inv_w), w)); },
+                  [&](int e, const Slot &s) {
+                      const int l = fast_div(e, inv_w), j = e - mul24(l, w);
+                      drain_use(l, j, mul24(l, pitch) + phys(j), s);
+                  });
 }
 
 // (phase, amplitude) rows -> complex -> forward row FFT -> T (values_to_coeff, src/train/pyramid.py:99-107, + the row half of
@@ -624,40 +641,49 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_rows_from_polar_kernel(const 
     const int total = lines * w;
     const float inv_w = 1.0f / (float)w;
     const bool blu = a.pw.bluestein != 0;
-    for_slots(total,
-              [&](int e) {
-                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
-                  const size_t o = base[l] + j;
-                  Slot s;
-                  if (a.pm.complex_coeff) s.z = reinterpret_cast<const float2 *>(a.phase)[o];
-                  else s.z = make_float2(a.phase[o], a.amp[o]);
-                  if (blu) s.c = a.pw.chirp[j];
-                  return s;
-              },
-              [&](int e, const Slot &s) {
-                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
-                  float2 x = s.z;
-                  if (!a.pm.complex_coeff) {
-                      float sn, cs;
-                      sincosf(s.z.x, &sn, &cs);
-                      x = make_float2(cs * s.z.y, sn * s.z.y);
-                  }
-                  buf[mul24(l, pitch) + phys(j)] = load_value<false>(x, s.c, blu);
-              });
+    auto fill_load = [&](int l, int j) {
+        const size_t o = base[l] + j;
+        Slot s;
+        if (a.pm.complex_coeff) s.z = reinterpret_cast<const float2 *>(a.phase)[o];
+        else s.z = make_float2(a.phase[o], a.amp[o]);
+        if (blu) s.c = a.pw.chirp[j];
+        return s;
+    };
+    auto fill_use = [&](int idx, const Slot &s) {
+        float2 x = s.z;
+        if (!a.pm.complex_coeff) {
+            float sn, cs;
+            sincosf(s.z.x, &sn, &cs);
+            x = make_float2(cs * s.z.y, sn * s.z.y);
+        }
+        buf[idx] = load_value<false>(x, s.c, blu);
+    };
+    float2 *Trow = a.T + row0 * w;
+    auto drain_load = [&](int j) {
+        Slot s;
+        if (blu) s.c = a.pw.chirp[j];
+        return s;
+    };
+    auto drain_use = [&](int l, int j, int idx, const Slot &s) { Trow[mul24(l, w) + j] = store_value<false>(buf[idx], s.c, blu); };
+    const bool wide = w >= kThreads;
+    if (wide)
+        for_rows(lines, w, pitch, [&](int l, int j, int) { return fill_load(l, j); },
+                 [&](int, int, int, int idx, const Slot &s) { fill_use(idx, s); });
+    else
+        for_slots(total, [&](int e) { const int l = fast_div(e, inv_w); return fill_load(l, e - mul24(l, w)); },
+                  [&](int e, const Slot &s) { const int l = fast_div(e, inv_w); fill_use(mul24(l, pitch) + phys(e - mul24(l, w)), s); });
     if (blu) zero_row_padding(buf, lines, pitch, w, m);
     lds_barrier();
     fft_lines(buf, lines, pitch, a.pw, twl);
-    float2 *Trow = a.T + row0 * w;
-    for_slots(total,
-              [&](int e) {
-                  Slot s;
-                  if (blu) s.c = a.pw.chirp[e - mul24(fast_div(e, inv_w), w)];
-                  return s;
-              },
-              [&](int e, const Slot &s) {
-                  const int l = fast_div(e, inv_w), j = e - mul24(l, w);
-                  Trow[e] = store_value<false>(buf[mul24(l, pitch) + phys(j)], s.c, blu);
-              });
+    if (wide)
+        for_rows(lines, w, pitch, [&](int, int j, int) { return drain_load(j); },
+                 [&](int l, int j, int, int idx, const Slot &s) { drain_use(l, j, idx, s); });
+    else
+        for_slots(total, [&](int e) { return drain_load(e - mul24(fast_div(e, inv_w), w)); },
+                  [&](int e, const Slot &s) {
+                      const int l = fast_div(e, inv_w), j = e - mul24(l, w);
+                      drain_use(l, j, mul24(l, pitch) + phys(j), s);
+                  });
 }
 
 struct CombineColsArgs {
@@ -680,28 +706,29 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_combine_cols_kernel(const Com
     if (tile >= ntiles) return;
     const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);
     const int v0 = tile * C, lines = w - v0 < C ? w - v0 : C;
-    const int shift = __ffs(C) - 1, total = h * C;
+    const int shift = __ffs(C) - 1;
     const bool blu = a.ph.bluestein != 0;
     const size_t hw = (size_t)h * w;
-    float2 *cur = a.cur + (size_t)n * hw + v0;
+    float2 *cur = a.cur + (size_t)n * hw;
     float2 *twl = buf + (size_t)C * pitch;
     load_twiddles(twl, a.ph);
+    const int ccm = tid & (C - 1);
+    const bool ccok = ccm < lines;
+    const int vt = v0 + (ccok ? ccm : 0), tb = mul24(tid >> shift, w) + vt;      // (for_tile: this thread's column)
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
-        const float2 *Tb = a.T + ((size_t)n * NB + b) * hw + v0;
+        const float2 *Tb = a.T + ((size_t)n * NB + b) * hw;
         const float *Pb = a.P + (size_t)b * hw;
-        for_slots(total,
-                  [&](int e) {
-                      const int u = e >> shift, cc = e & (C - 1);
-                      Slot s;
-                      s.z = Tb[mul24(u, w) + (cc < lines ? cc : 0)];
-                      if (blu) s.c = a.ph.chirp[u];
-                      return s;
-                  },
-                  [&](int e, const Slot &s) {
-                      const int u = e >> shift, cc = e & (C - 1);
-                      if (cc < lines) buf[mul24(cc, pitch) + phys(u)] = load_value<false>(s.z, s.c, blu);
-                  });
+        for_tile(h, shift, pitch,
+                 [&](int u, int uq, int) {
+                     Slot s;
+                     s.z = Tb[tb + mul24(uq, w)];
+                     if (blu) s.c = a.ph.chirp[u];
+                     return s;
+                 },
+                 [&](int, int, int, int idx, const Slot &s) {
+                     if (ccok) buf[idx] = load_value<false>(s.z, s.c, blu);
+                 });
         if (blu) {
             const int totz = (m - h) * C;
             for (int e = tid; e < totz; e += kThreads) {
@@ -713,12 +740,12 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_combine_cols_kernel(const Com
         fft_lines(buf, lines, pitch, a.ph, twl);
         // drain: band 0 starts the sum from the embedded coarser level, bands 1.. add to what this thread wrote for the
         // previous band (its own elements: still in L2)
-        for_slots(total,
-                  [&](int e) {
-                      const int u = e >> shift, cc = e & (C - 1), v = v0 + (cc < lines ? cc : 0);
+        for_tile(h, shift, pitch,
+                 [&](int u, int uq, int) {
+                      const int v = vt, o = tb + mul24(uq, w);
                       Slot s;
                       if (blu) s.c = a.ph.chirp[u];
-                      s.s = Pb[mul24(u, w) + v];
+                      s.s = Pb[o];
                       if (b == 0) {
                           s.z = make_float2(0.0f, 0.0f);
                           if (a.res) {
@@ -731,18 +758,17 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_combine_cols_kernel(const Com
                               }
                           }
                       } else {
-                          s.z = cur[mul24(u, w) + (cc < lines ? cc : 0)];
+                          s.z = cur[o];
                       }
                       return s;
-                  },
-                  [&](int e, const Slot &s) {
-                      const int u = e >> shift, cc = e & (C - 1);
-                      if (cc < lines) {
-                          const float2 z = store_value<false>(buf[mul24(cc, pitch) + phys(u)], s.c, blu);
+                 },
+                 [&](int, int uq, int, int idx, const Slot &s) {
+                      if (ccok) {
+                          const float2 z = store_value<false>(buf[idx], s.c, blu);
                           // * (-i) : (re, im) -> (im, -re)
-                          cur[mul24(u, w) + cc] = make_float2(s.z.x + z.y * s.s, s.z.y - z.x * s.s);
+                          cur[tb + mul24(uq, w)] = make_float2(s.z.x + z.y * s.s, s.z.y - z.x * s.s);
                       }
-                  });
+                 });
         lds_barrier();
     }
 }
