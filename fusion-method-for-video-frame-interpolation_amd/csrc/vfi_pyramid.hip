@@ -400,6 +400,7 @@ struct LevelColsArgs {
     float2 *hi_half;              // FIRST only
     const float *P, *lomask, *lo0, *hi0;
     int h, w, h2, w2, tile;
+    int bands_per_pass;           // 1, 2 or 4: how many bands go through ONE transform call as extra lines (small levels)
     float inv_hw;                 // FIRST: 1 / (H W) folded into the high-pass half spectrum
 };
 
@@ -483,16 +484,20 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_level_cols_kernel(const Level
                   });
     }
     if (!a.T) return;
-    float2 *twl = buf + (size_t)C * pitch;
+    float2 *twl = buf + (size_t)a.bands_per_pass * C * pitch;
     load_twiddles(twl, a.ph);
     // this thread's column of the tile (for_tile): validity, a safe column to read, offset of (row u0, that column)
     const int ccm = tid & (C - 1);
     const bool ccok = ccm < lines;
     const int vt = v0 + (ccok ? ccm : 0), tb = mul24(tid >> shift, w) + vt;
+    const int BP = a.bands_per_pass;          // bands per transform call: band bb of a pass occupies lines [bb*C, bb*C + C)
 #pragma unroll 1
-    for (int b = 0; b < NB; ++b) {
+    for (int b0 = 0; b0 < NB; b0 += BP) {
+      for (int bb = 0; bb < BP; ++bb) {
         // fill: conj(i * z * P_a[b]) (* chirp): the inverse transform runs as a forward one on conjugated data.  The tile
         // of z is re-read per band (L2) rather than kept in 70 registers across the stage calls.
+        const int b = b0 + bb;
+        float2 *bufb = buf + mul24(bb * C, pitch);
         const float *Pb = a.P + (size_t)b * hw;
         for_tile(h, shift, pitch,
                  [&](int u, int uq, int) {
@@ -510,18 +515,22 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_level_cols_kernel(const Level
                  },
                  [&](int, int, int, int idx, const Slot &s) {
                      if (ccok)      // * i : (re, im) -> (-im, re)
-                         buf[idx] = load_value<true>(make_float2(-(s.z.y * s.s), s.z.x * s.s), s.c, blu);
+                         bufb[idx] = load_value<true>(make_float2(-(s.z.y * s.s), s.z.x * s.s), s.c, blu);
                  });
         if (blu) {
             const int totz = (m - h) * C;
             for (int e = tid; e < totz; e += kThreads) {
                 const int u = h + (e >> shift), cc = e & (C - 1);
-                if (cc < lines) buf[cc * pitch + phys(u)] = make_float2(0.0f, 0.0f);
+                if (cc < lines) bufb[cc * pitch + phys(u)] = make_float2(0.0f, 0.0f);
             }
         }
+      }
         lds_barrier();
-        fft_lines(buf, lines, pitch, a.ph, twl);
-        float2 *Tb = a.T + ((size_t)n * NB + b) * hw;
+        // (a partial tile leaves unused lines between the bands of a pass: they are transformed too and never stored)
+        fft_lines(buf, BP > 1 ? BP * C : lines, pitch, a.ph, twl);
+      for (int bb = 0; bb < BP; ++bb) {
+        const float2 *bufb = buf + mul24(bb * C, pitch);
+        float2 *Tb = a.T + ((size_t)n * NB + b0 + bb) * hw;
         for_tile(h, shift, pitch,
                  [&](int u, int, int) {
                      Slot s;
@@ -529,8 +538,9 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_level_cols_kernel(const Level
                      return s;
                  },
                  [&](int, int uq, int, int idx, const Slot &s) {
-                     if (ccok) Tb[tb + mul24(uq, w)] = store_value<true>(buf[idx], s.c, blu);
+                     if (ccok) Tb[tb + mul24(uq, w)] = store_value<true>(bufb[idx], s.c, blu);
                  });
+      }
         lds_barrier();
     }
 }
@@ -693,6 +703,7 @@ struct CombineColsArgs {
     float2 *cur;                  // N x h x w
     const float *P, *lomask;
     int h, w, h2, w2, tile;
+    int bands_per_pass;
 };
 
 // cur = sum_b (-i) * FFTcol(T_b) * P_s[b]  +  embed(res * lomask)     (reconstruct: orientdft + resdft)
@@ -710,15 +721,17 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_combine_cols_kernel(const Com
     const bool blu = a.ph.bluestein != 0;
     const size_t hw = (size_t)h * w;
     float2 *cur = a.cur + (size_t)n * hw;
-    float2 *twl = buf + (size_t)C * pitch;
+    const int BP = a.bands_per_pass;
+    float2 *twl = buf + (size_t)BP * C * pitch;
     load_twiddles(twl, a.ph);
     const int ccm = tid & (C - 1);
     const bool ccok = ccm < lines;
     const int vt = v0 + (ccok ? ccm : 0), tb = mul24(tid >> shift, w) + vt;      // (for_tile: this thread's column)
 #pragma unroll 1
-    for (int b = 0; b < NB; ++b) {
-        const float2 *Tb = a.T + ((size_t)n * NB + b) * hw;
-        const float *Pb = a.P + (size_t)b * hw;
+    for (int b0 = 0; b0 < NB; b0 += BP) {
+      for (int bb = 0; bb < BP; ++bb) {
+        const float2 *Tb = a.T + ((size_t)n * NB + b0 + bb) * hw;
+        float2 *bufb = buf + mul24(bb * C, pitch);
         for_tile(h, shift, pitch,
                  [&](int u, int uq, int) {
                      Slot s;
@@ -727,17 +740,22 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_combine_cols_kernel(const Com
                      return s;
                  },
                  [&](int, int, int, int idx, const Slot &s) {
-                     if (ccok) buf[idx] = load_value<false>(s.z, s.c, blu);
+                     if (ccok) bufb[idx] = load_value<false>(s.z, s.c, blu);
                  });
         if (blu) {
             const int totz = (m - h) * C;
             for (int e = tid; e < totz; e += kThreads) {
                 const int u = h + (e >> shift), cc = e & (C - 1);
-                if (cc < lines) buf[cc * pitch + phys(u)] = make_float2(0.0f, 0.0f);
+                if (cc < lines) bufb[cc * pitch + phys(u)] = make_float2(0.0f, 0.0f);
             }
         }
+      }
         lds_barrier();
-        fft_lines(buf, lines, pitch, a.ph, twl);
+        fft_lines(buf, BP > 1 ? BP * C : lines, pitch, a.ph, twl);
+      for (int bb = 0; bb < BP; ++bb) {
+        const int b = b0 + bb;
+        const float2 *bufb = buf + mul24(bb * C, pitch);
+        const float *Pb = a.P + (size_t)b * hw;
         // drain: band 0 starts the sum from the embedded coarser level, bands 1.. add to what this thread wrote for the
         // previous band (its own elements: still in L2)
         for_tile(h, shift, pitch,
@@ -764,11 +782,12 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_combine_cols_kernel(const Com
                  },
                  [&](int, int uq, int, int idx, const Slot &s) {
                       if (ccok) {
-                          const float2 z = store_value<false>(buf[idx], s.c, blu);
+                          const float2 z = store_value<false>(bufb[idx], s.c, blu);
                           // * (-i) : (re, im) -> (im, -re)
                           cur[tb + mul24(uq, w)] = make_float2(s.z.x + z.y * s.s, s.z.y - z.x * s.s);
                       }
                  });
+      }
         lds_barrier();
     }
 }
@@ -782,6 +801,29 @@ void allow_big_lds(K kernel) {      // > 64 KiB of dynamic LDS needs the attribu
                                   (int)(vfi::fft::kLdsElems * sizeof(float2) + 8192));
         d = true;
     }
+}
+
+// Column tile width and bands per transform call of a fused level kernel: large levels take the widest tile that fits
+// and one band per call; small levels (latency-bound: few workgroups, each a chain of short phases) put 2 or all 4 bands
+// through one call as extra lines, with tiles of >= 8 columns.
+void level_tiling(const vfi::fft::Plan1D &ph, int w, int *tile, int *bands) {
+    using namespace vfi::fft;
+    *tile = cols_per_group(ph, w);
+    *bands = 1;
+    for (int bp : {4, 2}) {
+        int c = *tile;
+        while (c > 8 && (bp * c * ph.m > max_elems(ph) || bp * c * col_pitch(ph, c) + ph.tw_len > kLdsElems)) c /= 2;
+        if (c >= 8 || c == *tile) {
+            if (bp * c * ph.m <= max_elems(ph) && bp * c * col_pitch(ph, c) + ph.tw_len <= kLdsElems) {
+                *tile = c;
+                *bands = bp;
+                return;
+            }
+        }
+    }
+}
+size_t level_lds_bytes(const vfi::fft::Plan1D &ph, int tile, int bands) {
+    return ((size_t)bands * tile * vfi::fft::col_pitch(ph, tile) + ph.tw_len) * sizeof(float2);
 }
 
 // ---- 2-D transforms = a row pass and a column pass of the LDS engine (vfi_fft.h / vfi_fft.hip) ---------------------------
@@ -990,10 +1032,12 @@ extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *
         using namespace vfi::fft;
         Plan1D ph, pw;
         if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw))) return rc;
+        int tile, bpp;
+        level_tiling(ph, L.w, &tile, &bpp);
         LevelColsArgs ca{ph, src, p->bands, need_next ? next : nullptr, k == 0 && high ? p->half_hi : nullptr, L.P_a, L.lomask,
-                         p->lo0, p->hi0, L.h, L.w, h2, w2, cols_per_group(ph, L.w), 1.0f / ((float)H * (float)W)};
+                         p->lo0, p->hi0, L.h, L.w, h2, w2, tile, bpp, 1.0f / ((float)H * (float)W)};
         const dim3 cgrid(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N);
-        const size_t clds = col_lds_bytes(ph, ca.tile);
+        const size_t clds = level_lds_bytes(ph, tile, bpp);
         if (k == 0) {
             allow_big_lds(pyr_level_cols_kernel<true, 4>);
             hipLaunchKernelGGL((pyr_level_cols_kernel<true, 4>), cgrid, dim3(kThreads), clds, s, ca);
@@ -1065,10 +1109,12 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
         allow_big_lds(pyr_rows_from_polar_kernel<4>);
         hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
                            row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
-        CombineColsArgs ca{ph, p->bands, res, cur, L.P_s, L.lomask, L.h, L.w, h2, w2, cols_per_group(ph, L.w)};
+        int tile, bpp;
+        level_tiling(ph, L.w, &tile, &bpp);
+        CombineColsArgs ca{ph, p->bands, res, cur, L.P_s, L.lomask, L.h, L.w, h2, w2, tile, bpp};
         allow_big_lds(pyr_combine_cols_kernel<4>);
         hipLaunchKernelGGL((pyr_combine_cols_kernel<4>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
-                           col_lds_bytes(ph, ca.tile), s, ca);
+                           level_lds_bytes(ph, tile, bpp), s, ca);
         res = cur;
     }
     const float2 *hi_half = nullptr;
