@@ -59,6 +59,7 @@ class FusionInterpolator:
         self.device = torch.device(device) if device is not None else next(fusion_net.parameters()).device
         self.phase_net_state = phase_net_state
         self._per_size = {}
+        self._sides_model = getattr(adacof_model, "model", adacof_model)        # the AdaCoFNet behind the Model wrapper
 
     def _state(self, h, w):
         key = (h, w)
@@ -82,6 +83,18 @@ class FusionInterpolator:
         lab1, lab2 = ops.rgb2lab(rgb_frame1), ops.rgb2lab(rgb_frame2)                  # :148-149
         f1, f2 = rgb_frame1.unsqueeze(0), rgb_frame2.unsqueeze(0)
 
+        # the fused path never uses the two sampled sides (:156,229-237): have the sampler skip their stores
+        keep = getattr(self._sides_model, "return_sides", None)
+        if keep is not None:
+            self._sides_model.return_sides = False
+        try:
+            return self._run(rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2)
+        finally:
+            if keep is not None:
+                self._sides_model.return_sides = keep
+
+    def _run(self, rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2):
+        h, w = rgb_frame1.shape[1:]
         _, _, ada_pred, flow_var_map = self.adacof(f1, f2)                             # :156  (1,3,H,W), (1,1,H,W)
 
         # PhaseNet branch (:168-192)

@@ -72,6 +72,8 @@ WINOGRAD = os.environ.get("VFI_CONV_WINOGRAD", "1") != "0"     # mirrors the lib
 # 3x3 convs whose input is a bilinear resize: materialise the resize and use the Winograd kernel (default), or keep the
 # direct kernels with the interpolating tile loader (VFI_CONV_FUSED_RESIZE=1; always when Winograd is off)
 FUSED_RESIZE = (not WINOGRAD) or os.environ.get("VFI_CONV_FUSED_RESIZE", "0") == "1"
+# (measured again in round 2 for the thin 25 -> 25 head convolutions alone: the fused loader loses there too,
+# 77.5 vs 72.2 ms per frame)
 _WORKSPACES = {}
 WORKSPACE_FLOATS = 48 * 1024 * 1024     # 192 MiB per (device, stream): split-K partial sums of the deep U-Net levels
 
