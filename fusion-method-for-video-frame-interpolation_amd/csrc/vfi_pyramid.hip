@@ -7,20 +7,22 @@
 // oracle/pyramid_cpu.py: level k works on the centred ceil(H/s^k) x ceil(W/s^k) window of the
 // spectrum, radial raised-cosine transition shifted by log2(s) per level, nbands oriented analytic bands.
 //
-// Roofline: HBM.  FFTs are plain library transforms (hipFFT, plans cached in the plan object); everything
-// around them is fused into three kernels per level so that no intermediate of the reference's
-// op-by-op chain (mask products, crops, shifts, deepcopy, 2*L*N*4 atan2/abs launches) is materialised:
-//   analysis  : level kernel  : reads the running low-pass spectrum ONCE, writes the nbands band spectra
-//                               (mask * i rotation applied, ifftshift by index arithmetic) and the cropped,
-//                               low-pass filtered spectrum of the next level; level 0 also expands the R2C
-//                               half spectrum and emits the high-pass half spectrum for a C2R transform;
-//               polar kernel  : complex band -> (phase, amplitude) written straight into the caller's
+// Roofline: HBM (target).  Every transform runs on the hand-written LDS FFT engine of vfi_fft.h (mixed-radix Stockham +
+// Bluestein; no FFT library is linked), and each pyramid level is two fused kernels per direction, so that no
+// intermediate of the reference's op-by-op chain (mask products, crops, shifts, deepcopy, band spectra, band
+// coefficients, 2*L*N*4 atan2/abs launches) is materialised except ONE half-transformed array T:
+//   analysis  : column kernel : (column tile, image): reads the running low-pass spectrum, for each band multiplies by
+//                               the mask (i rotation applied, ifftshift by index arithmetic), inverse column FFT -> T;
+//                               also writes the cropped, low-pass filtered spectrum of the next level; level 0 also
+//                               expands the R2C half spectrum and emits the high-pass half spectrum for a C2R transform;
+//               row kernel    : rows of T -> inverse row FFT -> (phase, amplitude) written straight into the caller's
 //                               layout (per-image planes or PhaseNet's concat buffers), optional phase scale;
-//   synthesis : to-complex kernel (A cos p, A sin p), forward FFT, combine kernel (sum of rotated, masked
-//               band spectra + embedded low-pass of the coarser level).
+//   synthesis : row kernel (A cos p, A sin p -> forward row FFT -> T), column kernel (forward column FFT, sum of
+//               rotated, masked band spectra + embedded low-pass of the coarser level).
+// Levels that a level mask excludes only pass the low-pass spectrum along (pyr_analysis_level_kernel /
+// pyr_combine_kernel without bands).
 // All mask tables are precomputed once per plan in double precision, stored in the unshifted (FFT-native)
-// index order so every table read is coalesced with the spectrum access; a thread owns one frequency bin
-// and loops over the N images, so tables are read once per level, not once per image.
+// index order so every table read is coalesced with the spectrum access.
 #include "vfi_common.h"
 #include "vfi_fft.h"
 

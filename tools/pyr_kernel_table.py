@@ -12,7 +12,8 @@ for r in rows:
     if "pyr" not in n and "fft" not in n:
         continue
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    short = n.split("(")[0].replace("void ", "").replace("vfi::fft::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:30]
+    short = n.replace("void ", "").replace("vfi::fft::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    short = short.split("(")[0].split("<")[0][:30]
     k = (short, int(r["Grid_Size_X"]) // 256, int(r["Grid_Size_Y"]))
     agg[k][0] += 1
     agg[k][1] += d
