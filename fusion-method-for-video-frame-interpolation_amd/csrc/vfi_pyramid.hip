@@ -368,6 +368,18 @@ __global__ __launch_bounds__(256) void pyr_final_kernel(float2 *__restrict__ cur
     }
 }
 
+// a = a * ga + b * gb on half spectra (gains already include 1/(H*W))
+__global__ void pyr_gain_pair_kernel(float2 *__restrict__ a, const float2 *__restrict__ b, const float *__restrict__ ga,
+                                     const float *__restrict__ gb, int N, long long per_image) {
+    const long long total = (long long)N * per_image;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long j = i % per_image;
+        const float x = ga[j], y = gb[j];
+        const float2 za = a[i], zb = b[i];
+        a[i] = make_float2(za.x * x + zb.x * y, za.y * x + zb.y * y);
+    }
+}
+
 // half spectrum *= gain (already includes 1/(H*W) for the un-normalised C2R)
 __global__ void pyr_gain_kernel(float2 *__restrict__ half, const float *__restrict__ gain, int N, long long per_image) {
     const long long total = (long long)N * per_image;
@@ -982,6 +994,24 @@ extern "C" int vfi_pyr_apply_filter(vfi_pyr_plan *p, int filter_id, const float 
     hipLaunchKernelGGL(pyr_gain_kernel, dim3(blocks_1d(per * N)), dim3(256), 0, s, p->half0, p->filters[filter_id], N, per);
     if ((rc = fft2d_c2r(p, p->half0, out, N, s))) return rc;
     return vfi::check_launch("vfi_pyr_apply_filter");
+}
+
+extern "C" int vfi_pyr_apply_filter_pair(vfi_pyr_plan *p, int filter_a, const float *img_a, int filter_b, const float *img_b,
+                                         int N, float *out, vfi_stream_t stream) {
+    VFI_REQUIRE(p && img_a && img_b && out, VFI_ERR_INVALID_ARG, "vfi_pyr_apply_filter_pair: null pointer");
+    const int nf = (int)p->filters.size();
+    VFI_REQUIRE(filter_a >= 0 && filter_a < nf && filter_b >= 0 && filter_b < nf, VFI_ERR_INVALID_ARG,
+                "vfi_pyr_apply_filter_pair: bad filter ids %d, %d", filter_a, filter_b);
+    VFI_REQUIRE(N >= 1 && 2 * N <= p->max_images, VFI_ERR_INVALID_ARG, "vfi_pyr_apply_filter_pair: N=%d (plan max %d images in all)",
+                N, p->max_images);
+    hipStream_t s = vfi::as_stream(stream);
+    int rc;
+    if ((rc = fft2d_r2c(p, img_a, p->half0, N, s)) || (rc = fft2d_r2c(p, img_b, p->half_hi, N, s))) return rc;
+    const long long per = (long long)p->H * (p->W / 2 + 1);
+    hipLaunchKernelGGL(pyr_gain_pair_kernel, dim3(blocks_1d(per * N)), dim3(256), 0, s, p->half0, p->half_hi, p->filters[filter_a],
+                       p->filters[filter_b], N, per);
+    if ((rc = fft2d_c2r(p, p->half0, out, N, s))) return rc;
+    return vfi::check_launch("vfi_pyr_apply_filter_pair");
 }
 
 extern "C" int vfi_pyr_plan_destroy(vfi_pyr_plan *p) {

@@ -53,6 +53,7 @@ SIGNATURES = {
     "vfi_pyr_plan_level_size": [ctypes.c_void_p, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
     "vfi_pyr_plan_prepare_filter": [ctypes.c_void_p, ctypes.c_ulonglong, c_i, c_i, ctypes.POINTER(c_i)],
     "vfi_pyr_apply_filter": [ctypes.c_void_p, c_i, c_f, c_i, c_f, c_s],
+    "vfi_pyr_apply_filter_pair": [ctypes.c_void_p, c_i, c_f, c_i, c_f, c_i, c_f, c_s],
     "vfi_pyr_analyze": [ctypes.c_void_p, c_f, c_i, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f,
                         c_fl, ctypes.c_ulonglong, c_i, c_s],
     "vfi_pyr_synthesize": [ctypes.c_void_p, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f,

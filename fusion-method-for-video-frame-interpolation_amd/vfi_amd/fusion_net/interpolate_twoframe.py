@@ -13,8 +13,9 @@ which performs the sequence of interpolate_twoframe.py:148-330 entirely on the M
 Differences from the reference's execution (not its results):
   * Pyramid, PhaseNet and their plans/weights are built once per frame size, not per frame (:124-137);
   * no host round trips (the reference leaves the GPU 5x per frame for skimage/scipy, :148-149,190,207-225);
-  * the uncertainty pyramids only transform the levels that are kept (level masks) and both `h_freq`
-    reconstructions run as one batch-6 synthesis;
+  * wherever pyramid values are only moved, not modified, between analysis and synthesis (both `h_freq`
+    reconstructions of the phase uncertainty, the `baseline` mix) the round trip is applied as ONE radial gain in
+    the frequency domain; the ada-uncertainty pyramids only transform the levels that are kept (level masks);
   * AdaCoF #2 and #3 are independent and run as one batch of two.
 """
 import math
@@ -133,13 +134,14 @@ class FusionInterpolator:
         out = {"phase_pred": pp, "ada_pred": ada_pred, "base": base, "flow_var_map": flow_var_map,
                "phase_uncertainty": phase_uncertainty, "ada_uncertainty": ada_uncertainty}
         if output_baseline:                                                            # :288-322
+            # baseline = inv_filter(high + coarse half of filter(lab_ada), fine half + low of filter(lab_phase)): every
+            # value is moved UNMODIFIED, so both analyses and the synthesis are linear radial filters (see
+            # vfi_pyr_apply_filter_pair): G_a * lab_ada + G_p * lab_phase with one inverse transform
             split = nlev // 2
-            # only the parts that survive the mix are transformed (level masks)
-            va = pyr.filter(ops.rgb2lab(ada_pred[0]), level_mask=((1 << nlev) - 1) & ~((1 << split) - 1), want_low=False)
-            vp = pyr.filter(ops.rgb2lab(phase_pred), level_mask=(1 << split) - 1, want_high=False)
-            mix = DecompValues(va.high_level, vp.phase[:split] + va.phase[split:],
-                               vp.amplitude[:split] + va.amplitude[split:], vp.low_level)
-            out["baseline"] = ops.lab2rgb(pyr.inv_filter(mix)).unsqueeze(0)
+            fine = (1 << split) - 1
+            lab = pyr.band_filter_pair(ops.rgb2lab(ada_pred[0]), dict(level_mask=((1 << nlev) - 1) & ~fine, keep_high=True),
+                                       ops.rgb2lab(phase_pred), dict(level_mask=fine, keep_low=True))
+            out["baseline"] = ops.lab2rgb(lab).unsqueeze(0)
 
         other = torch.cat((lab1, lab2), 0).unsqueeze(0)                                # :324-325 (1,6,H,W)
         maps = torch.stack((ada_uncertainty, phase_uncertainty, flow_var_map[:, 0]), 1)   # :326-327 (1,3,H,W)

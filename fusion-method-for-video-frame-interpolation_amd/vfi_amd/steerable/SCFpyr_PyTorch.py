@@ -77,6 +77,26 @@ class Plan:
                   _lib.stream_ptr(), work=("byte", 8.0 * n * self.h * self.w, "pyr_band_filter"))
         return out
 
+    def _filter_id(self, level_mask, keep_high, keep_low):
+        key = (int(level_mask), bool(keep_high), bool(keep_low))
+        if not hasattr(self, "_filters"):
+            self._filters = {}
+        if key not in self._filters:
+            fid = ctypes.c_int()
+            _lib.call("vfi_pyr_plan_prepare_filter", self._h, key[0], int(key[1]), int(key[2]), ctypes.byref(fid))
+            self._filters[key] = fid.value
+        return self._filters[key]
+
+    def band_filter_pair(self, img_a, spec_a, img_b, spec_b):
+        """band_filter(img_a, *spec_a) + band_filter(img_b, *spec_b) with one inverse transform; spec = (level_mask,
+        keep_high, keep_low)."""
+        fa, fb = self._filter_id(*spec_a), self._filter_id(*spec_b)
+        out = torch.empty_like(img_a)
+        n = img_a.shape[0]
+        _lib.call("vfi_pyr_apply_filter_pair", self._h, fa, _lib.dptr(img_a, "img_a"), fb, _lib.dptr(img_b, "img_b"), n,
+                  out.data_ptr(), _lib.stream_ptr(), work=("byte", 12.0 * n * self.h * self.w, "pyr_band_filter_pair"))
+        return out
+
     def synthesize(self, high, phase, amp, table, low, mask, flags, img):
         n = img.shape[0]
         tab = (ctypes.c_int * len(table))(*table) if table is not None else None

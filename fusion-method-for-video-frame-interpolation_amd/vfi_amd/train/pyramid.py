@@ -103,6 +103,17 @@ class Pyramid:
         n, h, w = img.shape
         return self.pyr.plan(h, w, n).band_filter(img, level_mask, keep_high, keep_low)
 
+    def band_filter_pair(self, img_a, spec_a, img_b, spec_b):
+        """band_filter(img_a, **spec_a) + band_filter(img_b, **spec_b) (the sum of two unmodified level subsets of two
+        image sets, e.g. the reference's "baseline" mix) with one inverse transform.  spec = dict(level_mask=...,
+        keep_high=..., keep_low=...)."""
+        img_a, img_b = img_a.contiguous(), img_b.contiguous()
+        if img_a.shape != img_b.shape:
+            raise VfiLibraryError("band_filter_pair: shape mismatch")
+        n, h, w = img_a.shape
+        tup = lambda d: (d["level_mask"], d.get("keep_high", False), d.get("keep_low", False))
+        return self.pyr.plan(h, w, 2 * n).band_filter_pair(img_a, tup(spec_a), img_b, tup(spec_b))
+
     # -- synthesis -------------------------------------------------------------------------------------
     def inv_filter(self, vals):
         """Psi^{-1} filter: per-image DecompValues -> (N,H,W)."""

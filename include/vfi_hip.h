@@ -259,6 +259,13 @@ int vfi_pyr_plan_level_size(const vfi_pyr_plan *plan, int level, int *h, int *w)
 int vfi_pyr_plan_prepare_filter(vfi_pyr_plan *plan, unsigned long long level_mask, int keep_high, int keep_low,
                                 int *filter_id);
 int vfi_pyr_apply_filter(vfi_pyr_plan *plan, int filter_id, const float *img, int N, float *out, vfi_stream_t stream);
+/* out = real(ifft2(fft2(img_a) * G_a + fft2(img_b) * G_b)): the sum of two such filters applied to two image sets of N
+ * images each (2N <= the plan's max_images), one C2R.  Replaces the "baseline" mix of
+ * src/fusion_net/interpolate_twoframe.py:288-322 -- filter(lab_ada), filter(lab_phase), a DecompValues assembled from the
+ * fine levels + low residual of one and the coarse levels + high residual of the other, inv_filter -- which only moves
+ * UNMODIFIED values: two full analyses and one full synthesis become two R2C, one multiply-add and one C2R. */
+int vfi_pyr_apply_filter_pair(vfi_pyr_plan *plan, int filter_a, const float *img_a, int filter_b, const float *img_b, int N,
+                              float *out, vfi_stream_t stream);
 
 /* Pyramid.filter = SCFpyr_PyTorch.build + coeff_to_values (src/train/pyramid.py:35-39,48-78).
  *   img    (N, H, W)
