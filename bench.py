@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight per GPU (independent frames of the clip on separate HIP streams)")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture each in-flight frame's ~700 launches into a hipGraph (torch.cuda.CUDAGraph) and replay it")

@@ -16,7 +16,7 @@ Differences from the reference's execution (not its results):
   * wherever pyramid values are only moved, not modified, between analysis and synthesis (both `h_freq`
     reconstructions of the phase uncertainty, the `baseline` mix) the round trip is applied as ONE radial gain in
     the frequency domain; the ada-uncertainty pyramids only transform the levels that are kept (level masks);
-  * AdaCoF #2 and #3 are independent and run as one batch of two.
+  * AdaCoF #1, #2 and #3 are independent of each other and run as one batch of three (after the PhaseNet branch).
 """
 import math
 import os
@@ -96,13 +96,17 @@ class FusionInterpolator:
 
     def _run(self, rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2):
         h, w = rgb_frame1.shape[1:]
-        _, _, ada_pred, flow_var_map = self.adacof(f1, f2)                             # :156  (1,3,H,W), (1,1,H,W)
-
         # PhaseNet branch (:168-192)
         vals, bufs = pyr.filter(torch.cat((lab1, lab2), 0), concat_frames=2, phase_scale=1.0 / math.pi)
         vals_pred = phase_net(phase_net.normalize_vals(vals, concat=bufs))
         lab_pred = pyr.inv_filter(DecompValues(0, vals_pred.phase, vals_pred.amplitude, vals_pred.low_level))
         phase_pred = ops.lab2rgb(lab_pred)                                             # (3,H,W) rgb
+        pp = phase_pred.unsqueeze(0)
+
+        # AdaCoF #1 (rgb1, rgb2) (:156), #2 (rgb1, phase_pred) and #3 (phase_pred, rgb2) (:229-233) are independent of each
+        # other: ONE batch of three samples (the deep, small U-Net levels fill the chip better)
+        _, _, three, masks = self.adacof(torch.cat((f1, f1, pp), 0), torch.cat((f2, pp, f2), 0))
+        ada_pred, flow_var_map, between = three[:1], masks[:1], three[1:]              # (1,3,H,W), (1,1,H,W), (2,3,H,W)
 
         # uncertainty maps (:198-225)
         coarse = min(6, nlev)
@@ -126,9 +130,7 @@ class FusionInterpolator:
         fd = ops.channel_mean_diff(freq.unsqueeze(0), None, 30.0, False)               # :220
         ada_uncertainty = ops.absdiff(fd, ops.median_filter(fd, 50), 5.0, True)        # :221-225 (1,H,W)
 
-        # baseline (:228-238): AdaCoF on (rgb1, phase_pred), (phase_pred, rgb2), then on the two results
-        pp = phase_pred.unsqueeze(0)
-        _, _, between, _ = self.adacof(torch.cat((f1, pp), 0), torch.cat((pp, f2), 0))
+        # base (:234-238): AdaCoF #4 on the two intermediate results
         _, _, base, _ = self.adacof(between[:1], between[1:])
 
         out = {"phase_pred": pp, "ada_pred": ada_pred, "base": base, "flow_var_map": flow_var_map,
