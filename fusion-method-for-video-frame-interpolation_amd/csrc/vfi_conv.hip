@@ -430,7 +430,8 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
                        const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
                        int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, bool ups, float *workspace,
                        long long workspace_floats, vfi_stream_t stream, const float *x2 = nullptr, long long x2_bstride = 0,
-                       int rsz_channels = 0, int Hs = 0, int Ws = 0) {
+                       int rsz_channels = 0, int Hs = 0, int Ws = 0, float *pooled = nullptr, long long pooled_bstride = 0,
+                       int pool_max = 0) {
     VFI_REQUIRE(x && packed_w && y, VFI_ERR_INVALID_ARG, "vfi_conv2d: null pointer");
     VFI_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, VFI_ERR_INVALID_ARG, "vfi_conv2d: non-positive size");
     VFI_REQUIRE(KS == 1 || KS == 3 || KS == 5, VFI_ERR_UNSUPPORTED, "vfi_conv2d: kernel size %d", KS);
@@ -451,6 +452,7 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     a.ws = workspace_floats > 0 ? workspace : nullptr; a.ws_floats = workspace ? workspace_floats : 0; a.splits = 1;
     a.x2 = nullptr; a.x2_bs = 0; a.rsz_channels = 0; a.wino_tiles = 0; a.wino_items = 0; a.wino_batch = 0; a.wino_run = 1;
     a.Hs = H / 2; a.Ws = W / 2;
+    a.pool = nullptr; a.pool_bs = 0; a.pool_max = pool_max;
     a.ups_sy = H > 1 ? (float)(a.Hs - 1) / (float)(H - 1) : 0.0f;
     a.ups_sx = W > 1 ? (float)(a.Ws - 1) / (float)(W - 1) : 0.0f;
     hipStream_t s = vfi::as_stream(stream);
@@ -481,7 +483,13 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     const long long wino_work_items = (long long)a.tiles_x * vfi::ceil_div(H, 8) * N * (a.Cout_pad / 32) * 16;   // (x max. K split)
     if (KS == 3 && wino_on && (long long)Cin * H * W * 4 < (1ll << 32) && wino_work_items < (1ll << 30)) {
         a.wp = packed_w + (size_t)a.Cin_pad * 9 * a.Cout_pad;
+        a.pool = pooled; a.pool_bs = pooled_bstride;
         return launch_winograd(a, N, s);
+    }
+    if (pooled) {       // not a Winograd layer: the convolution, then the pooling pass
+        const int rc = conv2d_impl(x, x_bstride, packed_w, bias, residual, res_bstride, y, y_bstride, N, Cin, H, W, Cout, KS, pad_mode,
+                                   act, false, workspace, workspace_floats, stream);
+        return rc ? rc : vfi_pool2(y, y_bstride, pooled, pooled_bstride, N, Cout, H, W, pool_max, stream);
     }
     if (KS == 3) return wide ? launch_conv<3, 8, 2>(a, N, s) : launch_conv<3, 8, 1>(a, N, s);
     if (KS == 5) return wide ? launch_conv<5, 4, 2>(a, N, s) : launch_conv<5, 4, 1>(a, N, s);
@@ -494,6 +502,16 @@ extern "C" int vfi_conv2d(const float *x, long long x_bstride, const float *pack
                           long long workspace_floats, vfi_stream_t stream) {
     return conv2d_impl(x, x_bstride, packed_w, bias, residual, res_bstride, y, y_bstride, N, Cin, H, W, Cout, KS,
                        pad_mode, act, false, workspace, workspace_floats, stream);
+}
+
+extern "C" int vfi_conv2d_pool2(const float *x, long long x_bstride, const float *packed_w, const float *bias, float *y,
+                                long long y_bstride, float *pooled, long long pooled_bstride, int is_max, int N, int Cin, int H, int W,
+                                int Cout, int KS, int pad_mode, int act, float *workspace, long long workspace_floats,
+                                vfi_stream_t stream) {
+    VFI_REQUIRE(pooled, VFI_ERR_INVALID_ARG, "vfi_conv2d_pool2: null pooled output");
+    VFI_REQUIRE(H >= 2 && W >= 2, VFI_ERR_INVALID_ARG, "vfi_conv2d_pool2: %dx%d cannot be pooled", H, W);
+    return conv2d_impl(x, x_bstride, packed_w, bias, nullptr, 0, y, y_bstride, N, Cin, H, W, Cout, KS, pad_mode, act, false,
+                       workspace, workspace_floats, stream, nullptr, 0, 0, 0, 0, pooled, pooled_bstride, is_max ? 1 : 0);
 }
 
 extern "C" int vfi_conv2d_upsample2x(const float *x_lowres, long long x_bstride, const float *packed_w, const float *bias,

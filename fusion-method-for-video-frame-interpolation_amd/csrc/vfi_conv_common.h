@@ -25,6 +25,9 @@ struct ConvArgs {
     int wino_tiles, wino_items, wino_batch, wino_run;   // Winograd kernel: spatial tiles per sample; work items per K split; N; tiles per XCD run
     int Hs, Ws;    // UPS kernels: size of the low-resolution source x (H = 2*Hs, W = 2*Ws)
     float ups_sy, ups_sx;   // (Hs-1)/(H-1), (Ws-1)/(W-1): torch bilinear, align_corners=True
+    float *pool;            // Winograd kernel: optional second output, the 2x2 / stride-2 pooled result (N, Cout, H/2, W/2)
+    long long pool_bs;
+    int pool_max;           // 1: max pooling, 0: average
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

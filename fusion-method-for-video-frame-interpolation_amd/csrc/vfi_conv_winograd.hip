@@ -101,7 +101,9 @@ __device__ __forceinline__ Item decode_item(const ConvArgs &a, int L) {
 // in every item epilogue, so layers without a residual get an instantiation without them.
 // ACT: the activation as a compile-time constant (-1: read it from the arguments) -- the epilogue applies it to 64 values
 // per lane, and five inlined branches per value are most of the kernel's code size.
-template <bool RES, int ACT>
+// POOL: the lane that holds a 2x2 output block also writes its pooled value (AvgPool2d / MaxPool2d(2) after the layer,
+// src/fusion_net/fusion_adacofnet.py:76-89, src/fusion_net/fusion_net.py:41,59): no separate pass re-reads the output.
+template <bool RES, int ACT, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs a) {
     using T = WinoTile;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -356,6 +358,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
             // the upper output row of both tiles, the odd lane the lower row): 8 stores per lane instead of 16.
             const bool vec4 = it.x0 + T::TW <= a.W && it.y0 + T::TH <= a.H && (a.W % 4 == 0) && ((reinterpret_cast<size_t>(yp) & 15) == 0) &&
                               (!resp || (reinterpret_cast<size_t>(resp) & 15) == 0);
+            // pooled output: this lane's 2x2 block -> pixel (gy0/2, gxw/2) of the (H/2, W/2) plane
+            const int Hq = a.H >> 1, Wq = a.W >> 1;
+            float *__restrict__ pq = POOL ? a.pool + (size_t)it.n * a.pool_bs + (size_t)co0 * Hq * Wq + (size_t)(gy0 >> 1) * Wq + (gxw >> 1) : nullptr;
+            const bool pool_ok = POOL && (gy0 >> 1) < Hq && (gxw >> 1) < Wq;
+            auto pooled = [&](const float2 (&o)[2], float b) {
+                const float p0 = apply_act(o[0].x + b, act), p1 = apply_act(o[0].y + b, act);
+                const float p2 = apply_act(o[1].x + b, act), p3 = apply_act(o[1].y + b, act);
+                return a.pool_max ? fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)) : (p0 + p1 + p2 + p3) * 0.25f;      // (same order as vfi_pool2)
+            };
             if (vec4) {
                 const bool odd = n16 & 1;
                 const size_t off = (size_t)co0 * HW + (size_t)(gy0 + (odd ? 1 : 0)) * a.W + (gxw & ~3);
@@ -366,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
                         const int dc = mb * 16 + j;            // channel step from co0
                         float2 o[2];
                         outputs(mb, j, o);
+                        if (POOL && pool_ok && co0 + dc < a.Cout) pq[(size_t)dc * Hq * Wq] = pooled(o, bias_l[dc]);
                         // quad_perm [1,0,3,2]: exchange with the neighbouring tile column
                         const float2 give = odd ? o[0] : o[1];
                         float2 got;
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
                         float2 o[2];
                         outputs(mb, j, o);
                         const float b = split_out ? 0.0f : bias_l[dc];
+                        if (POOL && pool_ok) pq[(size_t)dc * Hq * Wq] = pooled(o, b);
 #pragma unroll
                         for (int dy = 0; dy < 2; ++dy)
                             if (gy0 + dy < a.H) {
@@ -460,6 +473,7 @@ int vfi::conv::launch_winograd(const ConvArgs &a, int N, hipStream_t s) {
                               reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 2>),
                               reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 3>),
                               reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 4>),
+                              reinterpret_cast<const void *>(conv3x3_winograd_kernel<false, 1, true>),
                               reinterpret_cast<const void *>(conv3x3_winograd_kernel<true, -1>)})
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
         int dev = 0, cus = 0;
@@ -497,6 +511,12 @@ int vfi::conv::launch_winograd(const ConvArgs &a, int N, hipStream_t s) {
     const long long items = (long long)b.wino_items * b.splits;
     dim3 grid((unsigned)(items < resident ? items : resident));
     const int act = b.splits > 1 ? 0 : b.act;      // split-K: the reduce kernel applies bias / activation / residual
+    // pooled second output: in the epilogue when the layer is a plain ReLU layer in one piece, else a pass afterwards
+    const bool pool_fused = b.pool && b.splits == 1 && !b.res && act == 1;
+    if (pool_fused) {
+        hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 1, true>), grid, dim3(256), T::LDS_BYTES, s, b);
+        return vfi::check_launch("vfi_conv2d");
+    }
     if (b.res && b.splits == 1) hipLaunchKernelGGL((conv3x3_winograd_kernel<true, -1>), grid, dim3(256), T::LDS_BYTES, s, b);
     else if (act == 0) hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 0>), grid, dim3(256), T::LDS_BYTES, s, b);
     else if (act == 1) hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 1>), grid, dim3(256), T::LDS_BYTES, s, b);
@@ -504,5 +524,9 @@ int vfi::conv::launch_winograd(const ConvArgs &a, int N, hipStream_t s) {
     else if (act == 3) hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 3>), grid, dim3(256), T::LDS_BYTES, s, b);
     else hipLaunchKernelGGL((conv3x3_winograd_kernel<false, 4>), grid, dim3(256), T::LDS_BYTES, s, b);
     if (b.splits > 1) launch_splitk_reduce(b, N, s);
+    if (b.pool) {
+        const int rc = vfi_pool2(b.y, b.y_bs, b.pool, b.pool_bs, N, b.Cout, b.H, b.W, b.pool_max, s);
+        if (rc) return rc;
+    }
     return vfi::check_launch("vfi_conv2d");
 }

@@ -84,6 +84,12 @@ class KernelEstimation(PackedModule):
             x = ops.conv2d(x, pc, "zeros", "relu")
         return x
 
+    def _basic_pooled(self, convs, x):
+        """Basic block followed by AvgPool2d(2): -> (block output, pooled output), the pooling fused into the last conv."""
+        for pc in convs[:-1]:
+            x = ops.conv2d(x, pc, "zeros", "relu")
+        return ops.conv2d_pool2(x, convs[-1], False, "zeros", "relu")
+
     def _up(self, pc, x, skip):
         """Upsample(x2, align_corners=True) -> conv -> ReLU, + skip (fusion_adacofnet.py:28-33,128-146)."""
         return ops.conv2d(x, pc, "zeros", "relu", residual=skip, upsample2x=True)
@@ -91,12 +97,12 @@ class KernelEstimation(PackedModule):
     def forward_x6(self, x6, softmax=True):
         """softmax=False returns the Subnet_weight LOGITS (the sampler folds the softmax in)."""
         p = self.packed()
-        c1 = self._basic(p["moduleConv1"], x6)
-        c2 = self._basic(p["moduleConv2"], ops.pool2(c1, False))
-        c3 = self._basic(p["moduleConv3"], ops.pool2(c2, False))
-        c4 = self._basic(p["moduleConv4"], ops.pool2(c3, False))
-        c5 = self._basic(p["moduleConv5"], ops.pool2(c4, False))
-        x = self._basic(p["moduleDeconv5"], ops.pool2(c5, False))
+        c1, q1 = self._basic_pooled(p["moduleConv1"], x6)          # (c1 itself is not a skip connection; q = AvgPool2d(c))
+        c2, q2 = self._basic_pooled(p["moduleConv2"], q1)
+        c3, q3 = self._basic_pooled(p["moduleConv3"], q2)
+        c4, q4 = self._basic_pooled(p["moduleConv4"], q3)
+        c5, q5 = self._basic_pooled(p["moduleConv5"], q4)
+        x = self._basic(p["moduleDeconv5"], q5)
         x = self._up(p["moduleUpsample5"], x, c5)
         x = self._up(p["moduleUpsample4"], self._basic(p["moduleDeconv4"], x), c4)
         x = self._up(p["moduleUpsample3"], self._basic(p["moduleDeconv3"], x), c3)

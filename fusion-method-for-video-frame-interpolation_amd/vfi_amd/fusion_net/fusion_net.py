@@ -46,9 +46,8 @@ class FusionNet(PackedModule):
         assert c0 == self.in_channels
         skip = []
         for i in range(3):                                # fusion_net.py:55-59
-            x = ops.conv2d(x, p["enc"][i], "reflect", "relu")
-            skip.append(x)
-            x = ops.pool2(x, is_max=True)
+            s, x = ops.conv2d_pool2(x, p["enc"][i], True, "reflect", "relu")     # conv + ReLU, and its MaxPool2d(2)
+            skip.append(s)
         x = ops.conv2d(x, p["mid"], "reflect", None)      # :61
         for i, s in enumerate(skip[::-1]):                # :63-67
             x = ops.resize_bilinear(x, s.shape[2:], align_corners=False, relu_input=True, residual=s)

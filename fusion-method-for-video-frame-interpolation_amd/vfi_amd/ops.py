@@ -127,6 +127,28 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2
     return out
 
 
+def conv2d_pool2(x, pc, is_max, pad_mode="zeros", act="relu"):
+    """(act(conv(x) + bias), pool2 of it): one vfi_conv2d_pool2 call (the pooled tensor comes out of the conv's epilogue
+    for 3x3 ReLU layers)."""
+    n, cin, h, w = x.shape
+    if cin != pc.cin:
+        raise VfiLibraryError(f"conv2d_pool2: input has {cin} channels, weights expect {pc.cin}")
+    out, pooled = new((n, pc.cout, h, w), x), new((n, pc.cout, h // 2, w // 2), x)
+    xp, xs = _slice_ptr(x, "x")
+    ws = _workspace(x.device)
+    work = None
+    if _lib.PROFILE is not None:
+        if pc.ks == 3 and WINOGRAD:
+            work = ("flop", 2.0 * n * cin * pc.cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")
+        else:
+            work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w,
+                    f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}>")
+    _lib.call("vfi_conv2d_pool2", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), out.data_ptr(), out.stride(0),
+              pooled.data_ptr(), pooled.stride(0), int(bool(is_max)), n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act],
+              ws.data_ptr(), ws.numel(), _lib.stream_ptr(), work=work)
+    return out, pooled
+
+
 def conv2d_resized_prefix(x, x2, pc, pad_mode="reflect", act=None, out=None):
     """conv over [bilinear_resize(x2, align_corners=False) | x[:, C2:]] with C2 = x2.shape[1]; x is (N, Cin, H, W) whose
     first C2 channels are ignored (never written).  One launch, the resized maps are not materialised."""

@@ -142,6 +142,16 @@ int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const
                int H, int W, int Cout, int KS, int pad_mode, int act, float *workspace,
                long long workspace_floats, vfi_stream_t stream);
 
+/* vfi_conv2d followed by 2x2 / stride-2 pooling of its result (AvgPool2d after every encoder block of the U-Net,
+ * src/fusion_net/fusion_adacofnet.py:76-89,116-126; MaxPool2d in FusionNet, src/fusion_net/fusion_net.py:41,59):
+ * y as vfi_conv2d (no residual), pooled (N, Cout, H/2, W/2) = pool(y).  For KS = 3 ReLU layers the pooled value is
+ * written by the convolution's epilogue (the lane that holds a 2x2 output block averages / maximises it); other
+ * layers run the pooling pass afterwards.  Same results as the two calls. */
+int vfi_conv2d_pool2(const float *x, long long x_bstride, const float *packed_w, const float *bias, float *y,
+                     long long y_bstride, float *pooled, long long pooled_bstride, int is_max, int N, int Cin, int H, int W,
+                     int Cout, int KS, int pad_mode, int act, float *workspace, long long workspace_floats,
+                     vfi_stream_t stream);
+
 /* conv2d( nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)(x_lowres) ) in one launch: the
  * `Upsample -> Conv2d` pairs of KernelEstimation (src/fusion_net/fusion_adacofnet.py:28-33 and the heads'
  * tails :41-43,53-56,67-70).  x_lowres is (N, Cin, H/2, W/2); H, W are the OUTPUT size (even); the upsampled

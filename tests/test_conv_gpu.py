@@ -217,3 +217,19 @@ def test_winograd_conv_one_chunk_items_keep_their_bias(device):
     out = ops.conv2d(x.to(device), pc, "zeros", None)
     torch.cuda.synchronize()
     assert (out.cpu() - _ref(x.double(), wgt.double(), b.double(), 3, "zeros", None).float()).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,ks,is_max,pad", [(2, 6, 32, 64, 96, 3, False, "zeros"), (1, 64, 128, 40, 72, 3, True, "reflect"),
+                                                         (1, 32, 64, 37, 51, 3, False, "zeros"), (1, 512, 512, 8, 12, 3, False, "zeros"),
+                                                         (1, 18, 32, 40, 72, 5, True, "reflect")])
+def test_conv_with_fused_pooling_equals_conv_then_pool(n, cin, cout, h, w, ks, is_max, pad, device):
+    # vfi_conv2d_pool2: the pooled tensor written by the Winograd epilogue (3x3 ReLU layers in one piece), or by a pooling
+    # pass behind split-K / direct layers -- bit-identical to conv2d followed by pool2 either way; odd sizes floor
+    g = torch.Generator().manual_seed(h * w + cin)
+    x = torch.randn((n, cin, h, w), generator=g).to(device)
+    wgt = torch.randn((cout, cin, ks, ks), generator=g) / (ks * cin ** 0.5)
+    pc = ops.PackedConv(wgt, torch.randn((cout,), generator=g), device=device)
+    y, q = ops.conv2d_pool2(x, pc, is_max, pad, "relu")
+    y_ref = ops.conv2d(x, pc, pad, "relu")
+    assert torch.equal(y, y_ref)
+    assert q.shape == (n, cout, h // 2, w // 2) and torch.equal(q, ops.pool2(y_ref, is_max))
