@@ -59,6 +59,7 @@ struct vfi_pyr_plan {
     float2 *bands = nullptr;     // N x nb x H x W    band spectra / coefficients of the current level
     float2 *lod[2] = {nullptr, nullptr};   // N x H x W each: running low-pass spectrum (ping-pong)
     std::map<int, vfi::fft::Plan1D> fft1d;   // transform length -> tables (vfi_fft.h)
+    unsigned *amp_bits = nullptr;            // kMaxLevels * 4 words: vfi_pyr_analyze_max
     std::vector<void *> allocs;
     // kept for vfi_pyr_plan_prepare_filter
     std::vector<double> log_rad, xr0, yr, yir;
@@ -567,6 +568,8 @@ struct RowsPolarArgs {
     long long rows;               // planes * h
     int h, lines;
     float inv_hw, phase_scale;
+    unsigned *amp_max;            // analysis only, optional: [groups] bit patterns of the largest amplitude per image group
+    int groups;
 };
 
 // per-line output base (in elements of h*w planes): plane map applied once per row, not per element
@@ -616,6 +619,9 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_rows_polar_kernel(const RowsP
         if (blu) s.c = a.pw.chirp[j];
         return s;
     };
+    // per-group maximum of the amplitudes this thread writes (groups <= 4: one running value per group)
+    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool want_max = a.amp_max != nullptr;
     auto drain_use = [&](int l, int j, int idx, const Slot &s) {
         const float2 z = store_value<true>(buf[idx], s.c, blu);
         const float re = z.x * a.inv_hw, im = z.y * a.inv_hw;
@@ -623,8 +629,14 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_rows_polar_kernel(const RowsP
         if (a.pm.complex_coeff) {
             reinterpret_cast<float2 *>(a.phase)[o] = make_float2(re, im);
         } else {
+            const float am = sqrtf(re * re + im * im);
             a.phase[o] = atan2f(im, re) * a.phase_scale;
-            a.amp[o] = sqrtf(re * re + im * im);
+            a.amp[o] = am;
+            if (want_max) {
+                const int g = (int)(((row0 + l) / a.h) / NB) % a.groups;      // (uniform per line)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) gmax[t] = t == g ? fmaxf(gmax[t], am) : gmax[t];
+            }
         }
     };
     const bool wide = w >= kThreads;          // long rows: the structured walk (no per-element division)
@@ -646,6 +658,20 @@ __global__ __launch_bounds__(kThreads, 2) void pyr_rows_polar_kernel(const RowsP
                       const int l = fast_div(e, inv_w), j = e - mul24(l, w);
                       drain_use(l, j, mul24(l, pitch) + phys(j), s);
                   });
+    if (want_max) {        // 64-lane butterfly, then one atomic per wave and group (amplitudes are >= 0: their bit patterns order like the values)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float m = gmax[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if ((threadIdx.x & 63) == 0 && t < a.groups && m > 0.0f) atomicMax(a.amp_max + t, __float_as_uint(m));
+        }
+    }
+}
+
+__global__ void pyr_amp_max_finish_kernel(const unsigned *__restrict__ bits, float *__restrict__ out, int count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = __uint_as_float(bits[i]) + eps;
 }
 
 // (phase, amplitude) rows -> complex -> forward row FFT -> T (values_to_coeff, src/train/pyramid.py:99-107, + the row half of
@@ -939,6 +965,7 @@ extern "C" int vfi_pyr_plan_create(int H, int W, int height, int nbands, double 
     if (!rc) rc = dev_alloc(p, (void **)&p->bands, N * nbands * HW * sizeof(float2));
     if (!rc) rc = dev_alloc(p, (void **)&p->lod[0], N * HW * sizeof(float2));
     if (!rc) rc = dev_alloc(p, (void **)&p->lod[1], N * HW * sizeof(float2));
+    if (!rc) rc = dev_alloc(p, (void **)&p->amp_bits, kMaxLevels * 4 * sizeof(unsigned));
     if (rc) {
         if (rc == VFI_ERR_NOMEM) vfi::set_error("vfi_pyr_plan_create: device allocation failed");
         vfi_pyr_plan_destroy(p);
@@ -1029,16 +1056,20 @@ extern "C" int vfi_pyr_plan_level_size(const vfi_pyr_plan *p, int level, int *h,
     return VFI_OK;
 }
 
-extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *high, float *const *phase,
-                               float *const *amp, const int *plane_index, float *low, float phase_scale,
-                               unsigned long long level_mask, int flags, vfi_stream_t stream) {
+static int pyr_analyze_impl(vfi_pyr_plan *p, const float *img, int N, float *high, float *const *phase,
+                            float *const *amp, const int *plane_index, float *low, float phase_scale,
+                            unsigned long long level_mask, int flags, float *amp_max, int groups, float eps, vfi_stream_t stream) {
     VFI_REQUIRE(p && img, VFI_ERR_INVALID_ARG, "vfi_pyr_analyze: null pointer");
+    VFI_REQUIRE(!amp_max || (groups >= 1 && groups <= 4 && !(flags & VFI_PYR_COMPLEX_COEFF)), VFI_ERR_INVALID_ARG,
+                "vfi_pyr_analyze_max: groups must be 1..4 and the outputs (phase, amplitude)");
     VFI_REQUIRE(N >= 1 && N <= p->max_images, VFI_ERR_INVALID_ARG, "vfi_pyr_analyze: N=%d (plan max %d)", N, p->max_images);
     VFI_REQUIRE((phase && (amp || (flags & VFI_PYR_COMPLEX_COEFF))) || level_mask == 0, VFI_ERR_INVALID_ARG,
                 "vfi_pyr_analyze: null phase/amp tables");
     hipStream_t s = vfi::as_stream(stream);
     const int H = p->H, W = p->W, nb = p->nbands;
     int rc;
+    if (amp_max && hipMemsetAsync(p->amp_bits, 0, sizeof(unsigned) * p->nlev * groups, s) != hipSuccess)
+        return vfi::fail(VFI_ERR_LAUNCH, "vfi_pyr_analyze_max: memset");
     if ((rc = fft2d_r2c(p, img, p->half0, N, s))) return rc;
     const float2 *src = p->half0;
     for (int k = 0; k < p->nlev; ++k) {
@@ -1081,7 +1112,7 @@ extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *
         int lines = rows_per_group(pw, rows);
         if (lines > 256) lines = 256;
         RowsPolarArgs ra{pw, p->bands, phase[k], amp ? amp[k] : nullptr, make_map(plane_index, k, N, nb, flags), rows, L.h, lines,
-                         1.0f / ((float)L.h * (float)L.w), phase_scale};
+                         1.0f / ((float)L.h * (float)L.w), phase_scale, amp_max ? p->amp_bits + (size_t)k * groups : nullptr, groups};
         allow_big_lds(pyr_rows_polar_kernel<4>);
         hipLaunchKernelGGL((pyr_rows_polar_kernel<4>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
                            row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
@@ -1097,7 +1128,25 @@ extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *
     if (high) {  // high residual: C2R of half * hi0 / (H W)
         if ((rc = fft2d_c2r(p, p->half_hi, high, N, s))) return rc;
     }
+    if (amp_max) {
+        const int count = p->nlev * groups;
+        hipLaunchKernelGGL(pyr_amp_max_finish_kernel, dim3(ceil_div(count, 64)), dim3(64), 0, s, p->amp_bits, amp_max, count, eps);
+    }
     return vfi::check_launch("vfi_pyr_analyze");
+}
+
+extern "C" int vfi_pyr_analyze(vfi_pyr_plan *p, const float *img, int N, float *high, float *const *phase,
+                               float *const *amp, const int *plane_index, float *low, float phase_scale,
+                               unsigned long long level_mask, int flags, vfi_stream_t stream) {
+    return pyr_analyze_impl(p, img, N, high, phase, amp, plane_index, low, phase_scale, level_mask, flags, nullptr, 1, 0.0f, stream);
+}
+
+extern "C" int vfi_pyr_analyze_max(vfi_pyr_plan *p, const float *img, int N, float *high, float *const *phase,
+                                   float *const *amp, const int *plane_index, float *low, float phase_scale,
+                                   unsigned long long level_mask, int flags, float *amp_max, int groups, float eps,
+                                   vfi_stream_t stream) {
+    VFI_REQUIRE(amp_max, VFI_ERR_INVALID_ARG, "vfi_pyr_analyze_max: null amp_max");
+    return pyr_analyze_impl(p, img, N, high, phase, amp, plane_index, low, phase_scale, level_mask, flags, amp_max, groups, eps, stream);
 }
 
 extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const float *const *phase, const float *const *amp,
@@ -1137,7 +1186,7 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
         int lines = rows_per_group(pw, rows);
         if (lines > 256) lines = 256;
         RowsPolarArgs ra{pw, p->bands, const_cast<float *>(phase[k]), amp ? const_cast<float *>(amp[k]) : nullptr,
-                         make_map(plane_index, k, N, nb, flags), rows, L.h, lines, 1.0f, 1.0f};
+                         make_map(plane_index, k, N, nb, flags), rows, L.h, lines, 1.0f, 1.0f, nullptr, 1};
         allow_big_lds(pyr_rows_from_polar_kernel<4>);
         hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
                            row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "vfi_pyr_apply_filter_pair": [ctypes.c_void_p, c_i, c_f, c_i, c_f, c_i, c_f, c_s],
     "vfi_pyr_analyze": [ctypes.c_void_p, c_f, c_i, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f,
                         c_fl, ctypes.c_ulonglong, c_i, c_s],
+    "vfi_pyr_analyze_max": [ctypes.c_void_p, c_f, c_i, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f,
+                            c_fl, ctypes.c_ulonglong, c_i, c_f, c_i, c_fl, c_s],
     "vfi_pyr_synthesize": [ctypes.c_void_p, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f,
                            ctypes.c_ulonglong, c_i, c_f, c_i, c_s],
 }

@@ -97,8 +97,9 @@ class FusionInterpolator:
     def _run(self, rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2):
         h, w = rgb_frame1.shape[1:]
         # PhaseNet branch (:168-192)
-        vals, bufs = pyr.filter(torch.cat((lab1, lab2), 0), concat_frames=2, phase_scale=1.0 / math.pi)
-        vals_pred = phase_net(phase_net.normalize_vals(vals, concat=bufs))
+        vals, bufs, amp_max = pyr.filter(torch.cat((lab1, lab2), 0), concat_frames=2, phase_scale=1.0 / math.pi,
+                                         amp_max_eps=phase_net.eps)       # (the per-level maxima of :55 come with the bands)
+        vals_pred = phase_net(phase_net.normalize_vals(vals, concat=bufs, amp_max=amp_max))
         lab_pred = pyr.inv_filter(DecompValues(0, vals_pred.phase, vals_pred.amplitude, vals_pred.low_level))
         phase_pred = ops.lab2rgb(lab_pred)                                             # (3,H,W) rgb
         pp = phase_pred.unsqueeze(0)

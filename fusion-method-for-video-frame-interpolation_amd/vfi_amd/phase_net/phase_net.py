@@ -68,12 +68,12 @@ class PhaseNet(PackedModule):
         return out
 
     # -- normalisation (phase_net.py:42-78) -------------------------------------------------------------
-    def normalize_vals(self, vals, concat=None):
+    def normalize_vals(self, vals, concat=None, amp_max=None):
         """phase_net.py:42-78.  `concat` (from Pyramid.filter(concat_frames=2, phase_scale=1/pi)): the block-input
         buffers that already hold phase/pi and the raw amplitudes -- then only the maxima are computed and
         the amplitudes / low level are normalised in place (no copies)."""
         if concat is not None:
-            return self._normalize_in_place(vals, concat)
+            return self._normalize_in_place(vals, concat, amp_max)
         nlev = len(vals.phase)
         b = vals.amplitude[0].shape[0]
         maxes, concat, phases, amps = [], [], [], []
@@ -97,10 +97,11 @@ class PhaseNet(PackedModule):
         out.concat = concat
         return out
 
-    def _normalize_in_place(self, vals, concat):
+    def _normalize_in_place(self, vals, concat, amp_max=None):
+        """amp_max (levels coarsest first, colours): maxima + eps already reduced by Pyramid.filter(amp_max_eps=...)."""
         maxes = []
         for idx, amp in enumerate(vals.amplitude):          # views into concat[idx]
-            mx = ops.batch_max(amp, self.eps)
+            mx = amp_max[idx] if amp_max is not None else ops.batch_max(amp, self.eps)
             maxes.append(mx)
             ops.affine_slice(amp, amp, mx, 1.0)
         self.max_amplitudes = maxes

@@ -53,14 +53,19 @@ class Plan:
         px += sum(2 * self.nbands * a * b for k, (a, b) in enumerate(self.sizes[:-1]) if (mask >> k) & 1)
         return 4.0 * n * px
 
-    def analyze(self, img, high, phase, amp, table, low, phase_scale, mask, flags):
+    def analyze(self, img, high, phase, amp, table, low, phase_scale, mask, flags, amp_max=None, groups=1, eps=0.0):
+        """amp_max: optional (levels, groups) float tensor that receives max amplitude + eps per level and image group
+        (image d belongs to group d % groups): PhaseNet.normalize_vals' maxima, reduced by the kernel that writes them."""
         n = img.shape[0]
         tab = (ctypes.c_int * len(table))(*table) if table is not None else None
-        _lib.call("vfi_pyr_analyze", self._h, _lib.dptr(img, "img"), n,
-                  high.data_ptr() if torch.is_tensor(high) else None, _ptr_array(phase),
-                  _ptr_array(amp) if amp is not None else None, tab,
-                  low.data_ptr() if torch.is_tensor(low) else None, float(phase_scale), mask, flags, _lib.stream_ptr(),
-                  work=("byte", self._bytes(n, mask, torch.is_tensor(high), torch.is_tensor(low)), "pyr_analyze"))
+        head = (self._h, _lib.dptr(img, "img"), n, high.data_ptr() if torch.is_tensor(high) else None, _ptr_array(phase),
+                _ptr_array(amp) if amp is not None else None, tab, low.data_ptr() if torch.is_tensor(low) else None,
+                float(phase_scale), mask, flags)
+        work = ("byte", self._bytes(n, mask, torch.is_tensor(high), torch.is_tensor(low)), "pyr_analyze")
+        if amp_max is None:
+            _lib.call("vfi_pyr_analyze", *head, _lib.stream_ptr(), work=work)
+        else:
+            _lib.call("vfi_pyr_analyze_max", *head, _lib.dptr(amp_max, "amp_max"), int(groups), float(eps), _lib.stream_ptr(), work=work)
 
     def band_filter(self, img, level_mask, keep_high, keep_low):
         """real(ifft2(fft2(img) * G)): analysis + synthesis of an unmodified level subset as ONE radial filter."""

@@ -45,7 +45,7 @@ class Pyramid:
         self.pyr = SCFpyr_PyTorch(height=height, nbands=nbands, scale_factor=scale_factor, device=self.device)
 
     # -- analysis -------------------------------------------------------------------------------------
-    def filter(self, img, concat_frames=None, phase_scale=1.0, level_mask=None, want_high=True, want_low=True):
+    def filter(self, img, concat_frames=None, phase_scale=1.0, level_mask=None, want_high=True, want_low=True, amp_max_eps=None):
         """Psi filter.  img (N,H,W) -> DecompValues in the per-image layout: high (N,1,H,W),
         phase/amplitude[k] (N*nbands,1,h_k,w_k) finest first with index img*nbands+band, low (N,1,hL,wL).
 
@@ -87,12 +87,18 @@ class Pyramid:
         low = new(c, f, *sizes[nlev]) if want_low else 0
         hi_tmp = new(n, h, w) if want_high else 0
         lo_tmp = new(n, *sizes[nlev]) if want_low else 0
-        plan.analyze(img, hi_tmp, phase, amp, table, lo_tmp, phase_scale, mask, 0)
+        amp_max = None
+        if amp_max_eps is not None:        # (levels finest first, colours): max amplitude + eps, for PhaseNet.normalize_vals
+            amp_max = new(nlev, c)
+        plan.analyze(img, hi_tmp, phase, amp, table, lo_tmp, phase_scale, mask, 0, amp_max=amp_max, groups=c,
+                     eps=amp_max_eps if amp_max_eps is not None else 0.0)
         if want_high:
             high.copy_(hi_tmp.view(f, c, h, w).transpose(0, 1))
         if want_low:
             low.copy_(lo_tmp.view(f, c, *sizes[nlev]).transpose(0, 1))
         out = DecompValues(high, phase[::-1], amp[::-1], low)
+        if amp_max is not None:
+            return out, bufs[::-1], amp_max.flip(0).contiguous()      # coarsest first, like the lists
         return out, bufs[::-1]
 
     def band_filter(self, img, level_mask, keep_high=False, keep_low=False):

@@ -292,6 +292,14 @@ int vfi_pyr_apply_filter_pair(vfi_pyr_plan *plan, int filter_a, const float *img
 int vfi_pyr_analyze(vfi_pyr_plan *plan, const float *img, int N, float *high, float *const *phase,
                     float *const *amp, const int *plane_index, float *low, float phase_scale,
                     unsigned long long level_mask, int flags, vfi_stream_t stream);
+/* The same, plus the maxima PhaseNet.normalize_vals needs (src/phase_net/phase_net.py:55: max over the 8 channels
+ * x pixels of each colour, per level), reduced inside the row kernel that writes the amplitudes (wave shuffles, one
+ * atomic per wave): amp_max[k * groups + g] = max amplitude of level k over the images d with d % groups == g,
+ * + eps.  amp_max must hold (height-2) * groups floats; levels outside level_mask get eps. */
+int vfi_pyr_analyze_max(vfi_pyr_plan *plan, const float *img, int N, float *high, float *const *phase,
+                        float *const *amp, const int *plane_index, float *low, float phase_scale,
+                        unsigned long long level_mask, int flags, float *amp_max, int groups, float eps,
+                        vfi_stream_t stream);
 
 /* Pyramid.inv_filter = values_to_coeff + SCFpyr_PyTorch.reconstruct (src/train/pyramid.py:41-46,85-112).
  * high / low may be NULL (treated as zeros, e.g. PhaseNet's high_level, src/phase_net/phase_net.py:127-128);

@@ -163,3 +163,21 @@ def test_band_filter_equals_analysis_plus_masked_synthesis(device):
     # all levels + both residuals == identity
     full = pyr.band_filter(img.to(device), level_mask=(1 << nlev) - 1, keep_high=True, keep_low=True).cpu()
     assert (full - img).abs().max().item() <= 2e-5
+
+
+def test_amplitude_maxima_come_with_the_bands(device):
+    # Pyramid.filter(concat_frames=2, amp_max_eps=eps): the per-(level, colour) maxima PhaseNet.normalize_vals needs
+    # (src/phase_net/phase_net.py:55), reduced inside the kernel that writes the amplitudes -- equal, bit for bit, to a
+    # separate max over the written amplitudes
+    from vfi_amd import ops
+    h, w = 90, 120
+    height = layout_cpu.calc_pyr_height(h, w)
+    img = _images(8, 1, h, w).to(device)
+    pyr = Pyramid(height, 4, S2, device)
+    vals, bufs, amp_max = pyr.filter(img, concat_frames=2, phase_scale=1.0 / math.pi, amp_max_eps=1e-8)
+    assert amp_max.shape == (height - 2, 3)
+    for k, amp in enumerate(vals.amplitude):                  # coarsest first, (3, 8, h_k, w_k) views
+        assert torch.equal(amp_max[k], ops.batch_max(amp, 1e-8)), k
+    plain, _ = pyr.filter(img, concat_frames=2, phase_scale=1.0 / math.pi)
+    for a, b in zip(vals.amplitude, plain.amplitude):
+        assert torch.equal(a, b)
