@@ -118,7 +118,7 @@ def spawn_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not (have >= 1 and os.environ.get("VFI_BENCH_SHARE_GPUS") == "1"):     # (rehearsal: ranks share the GPUs)
         sys.exit(f"bench.py: --gpus {n} but this node shows {have} GPU(s)")
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
