@@ -214,6 +214,21 @@ VFI_HD int mul24(int a, int b) {
 VFI_HD int phys(int a) { return a + (a >> 5); }
 VFI_HD int padded_length(int m) { return m + ((m + 31) >> 5); }
 
+// Who transforms which lines.  Cooperative: all 256 threads share all lines (workgroup barriers between the halves of a
+// stage).  Wave-private (lines % 4 == 0): wave w owns lines w, w+4, ... and nobody else touches them between fill and
+// drain, so its stages need no workgroup barrier at all -- the four waves drift apart and their LDS / VALU / wait phases
+// overlap on the SIMDs instead of meeting at 2 x nstages barriers per transform.
+struct Team {
+    int tid, nthr;            // this thread's index in the team, team size (256 or 64)
+    int line0, line_step;     // the team's lines: line0 + line_step * i, i < nlines
+    int nlines;
+};
+VFI_HD Team team_all(int tid, int lines) { return Team{tid, kThreads, 0, 1, lines}; }
+VFI_HD Team team_wave(int tid, int lines) {
+    const int wave = tid >> 6;
+    return Team{tid & 63, 64, wave, kThreads / 64, (lines - wave + kThreads / 64 - 1) / (kThreads / 64)};
+}
+
 template <int R> struct StageRegs {
     static constexpr int QB = ((kMaxElems + R - 1) / R + kThreads - 1) / kThreads;   // butterflies per thread
     static constexpr int QBB = ((kMaxElemsB + R - 1) / R + kThreads - 1) / kThreads;  // ... of a Bluestein plan
@@ -229,10 +244,10 @@ template <int R> struct StageRegs {
 // All loads of all of a thread's butterflies (LDS operands, twiddles, filter) are issued before any arithmetic, so their
 // latencies overlap; out-of-range butterflies read butterfly 0 and are dropped by the scatter.
 template <int R, bool MULB>
-VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines, int pitch, int m, int p,
+VFI_HD void stage_gather(StageRegs<R> &s, const Team tm, const float2 *buf, int pitch, int m, int p,
                          const float2 *tw, int tw_len, const float2 *__restrict__ bfilt) {
     constexpr int QB = MULB ? StageRegs<R>::QBB : StageRegs<R>::QB, NW = StageRegs<R>::NW;
-    const int T = m / R, total = lines * T, twstep = m / (p * R);
+    const int T = m / R, total = tm.nlines * T, twstep = m / (p * R);
     // how many of W^e, W^2e, W^4e, W^8e (e < T) lie inside the LDS table; the others are formed by squaring (uniform)
     const int nload = T <= tw_len ? (2 * T <= tw_len ? (4 * T <= tw_len ? (8 * T <= tw_len ? 4 : 3) : 2) : 1) : 0;
     const float inv_T = 1.0f / (float)T, inv_p = 1.0f / (float)p;
@@ -240,10 +255,10 @@ VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines,
     float2 bf[MULB ? QB : 1][MULB ? R : 1];
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-        if (kThreads * q < total) {                    // (uniform)
-            const int t0 = tid + kThreads * q, t = t0 < total ? t0 : 0;
-            const int line = fast_div(t, inv_T), i = t - mul24(line, T), k = i - mul24(fast_div(i, inv_p), p);
-            const float2 *x = buf + mul24(line, pitch);
+        if (tm.nthr * q < total) {                     // (uniform per wave)
+            const int t0 = tm.tid + tm.nthr * q, t = t0 < total ? t0 : 0;
+            const int ll = fast_div(t, inv_T), i = t - mul24(ll, T), k = i - mul24(fast_div(i, inv_p), p);
+            const float2 *x = buf + mul24(tm.line0 + mul24(ll, tm.line_step), pitch);
 #pragma unroll
             for (int r = 0; r < R; ++r) s.v[q][r] = x[phys(i + mul24(r, T))];
             if (MULB) {
@@ -261,7 +276,7 @@ VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines,
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-        if (kThreads * q < total) {
+        if (tm.nthr * q < total) {
             if (MULB) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) s.v[q][r] = cconj(cmul(s.v[q][r], bf[MULB ? q : 0][MULB ? r : 0]));
@@ -289,15 +304,15 @@ VFI_HD void stage_gather(StageRegs<R> &s, int tid, const float2 *buf, int lines,
 }
 
 template <int R>
-VFI_HD void stage_scatter(const StageRegs<R> &s, int tid, float2 *buf, int lines, int pitch, int m, int p) {
-    const int T = m / R, total = lines * T;
+VFI_HD void stage_scatter(const StageRegs<R> &s, const Team tm, float2 *buf, int pitch, int m, int p) {
+    const int T = m / R, total = tm.nlines * T;
     const float inv_T = 1.0f / (float)T, inv_p = 1.0f / (float)p;
 #pragma unroll
     for (int q = 0; q < StageRegs<R>::QB; ++q) {
-        const int t = tid + kThreads * q;
+        const int t = tm.tid + tm.nthr * q;
         if (t < total) {
-            const int line = fast_div(t, inv_T), i = t - mul24(line, T), g = fast_div(i, inv_p), k = i - mul24(g, p);
-            float2 *y = buf + mul24(line, pitch);
+            const int ll = fast_div(t, inv_T), i = t - mul24(ll, T), g = fast_div(i, inv_p), k = i - mul24(g, p);
+            float2 *y = buf + mul24(tm.line0 + mul24(ll, tm.line_step), pitch);
             const int a0 = mul24(g, mul24(p, R)) + k;
 #pragma unroll
             for (int r = 0; r < R; ++r) y[phys(a0 + mul24(r, p))] = s.v[q][r];
@@ -408,25 +423,34 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Within one wave LDS operations execute in issue order, so a wave-private stage only has to stop the COMPILER from
+// moving its gather above the previous scatter (and wait for the reads it consumes, which the data dependence does).
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
 template <int R, bool MULB>
 __device__ __noinline__ void stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, int tw_len,
-                                   const float2 *__restrict__ bfilt) {
+                                   const float2 *__restrict__ bfilt, int wave_private) {
     StageRegs<R> s;
-    stage_gather<R, MULB>(s, threadIdx.x, buf, lines, pitch, m, p, tw, tw_len, bfilt);
-    lds_barrier();
-    stage_scatter<R>(s, threadIdx.x, buf, lines, pitch, m, p);
-    lds_barrier();
+    const Team tm = wave_private ? team_wave(threadIdx.x, lines) : team_all(threadIdx.x, lines);
+    stage_gather<R, MULB>(s, tm, buf, pitch, m, p, tw, tw_len, bfilt);
+    if (wave_private) wave_lds_order(); else lds_barrier();
+    stage_scatter<R>(s, tm, buf, pitch, m, p);
+    if (wave_private) wave_lds_order(); else lds_barrier();
 }
-__device__ __forceinline__ void stage_any(int R, float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, int tw_len) {
+__device__ __forceinline__ void stage_any(int R, float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, int tw_len, int wp) {
     switch (R) {
-        case 16: stage<16, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
-        case 15: stage<15, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
-        case 9: stage<9, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
-        case 8: stage<8, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
-        case 4: stage<4, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
-        case 2: stage<2, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
-        case 3: stage<3, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
-        default: stage<5, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr); break;
+        case 16: stage<16, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
+        case 15: stage<15, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
+        case 9: stage<9, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
+        case 8: stage<8, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
+        case 4: stage<4, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
+        case 2: stage<2, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
+        case 3: stage<3, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
+        default: stage<5, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
     }
 }
 // The workgroup's copy of the twiddle table: pl.tw_len entries behind the lines (call once, before the first fft_lines;
@@ -447,25 +471,30 @@ __device__ __forceinline__ void load_twiddles(float2 *twl, const Plan1D &pl) {
     }
 }
 // `lines` FORWARD transforms at buf[l * pitch + phys(j)]; results in place (see load_value / store_value).
-// twl: the LDS twiddle table filled by load_twiddles.
+// twl: the LDS twiddle table filled by load_twiddles.  The lines must be filled and published by a workgroup barrier;
+// on return every line is complete only after the CALLER's next workgroup barrier when the wave-private mode ran
+// (lines % 4 == 0): the callers barrier before draining anyway.
 __device__ __forceinline__ void fft_lines(float2 *buf, int lines, int pitch, const Plan1D &pl, const float2 *twl) {
+    const int wp = (lines & (kThreads / 64 - 1)) == 0 ? 1 : 0;
     int p = 1;
     for (int s = 0; s < pl.nstages; ++s) {
-        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, twl, pl.tw_len);
+        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, twl, pl.tw_len, wp);
         p *= pl.radix[s];
     }
-    if (!pl.bluestein) return;
-    switch (pl.radix[0]) {                  // (a Bluestein length is a power of two: radices 16, 8, 4, 2 only)
-        case 16: stage<16, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt); break;
-        case 8: stage<8, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt); break;
-        case 4: stage<4, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt); break;
-        default: stage<2, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt); break;
+    if (pl.bluestein) {
+        switch (pl.radix[0]) {                  // (a Bluestein length is a power of two: radices 16, 8, 4, 2 only)
+            case 16: stage<16, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt, wp); break;
+            case 8: stage<8, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt, wp); break;
+            case 4: stage<4, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt, wp); break;
+            default: stage<2, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt, wp); break;
+        }
+        p = pl.radix[0];
+        for (int s = 1; s < pl.nstages; ++s) {
+            stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, twl, pl.tw_len, wp);
+            p *= pl.radix[s];
+        }
     }
-    p = pl.radix[0];
-    for (int s = 1; s < pl.nstages; ++s) {
-        stage_any(pl.radix[s], buf, lines, pitch, pl.m, p, twl, pl.tw_len);
-        p *= pl.radix[s];
-    }
+    if (wp) lds_barrier();      // the drain is cooperative again
 }
 
 // ---- host-side planning ----------------------------------------------------------------------------------------------

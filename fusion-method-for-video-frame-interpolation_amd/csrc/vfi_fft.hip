@@ -221,6 +221,7 @@ int rows_per_group(const Plan1D &pl, long long total_rows) {
     if (l < min_l) l = min_l;
     if (l > max_lines(pl)) l = max_lines(pl);
     if (l > total_rows) l = total_rows;
+    if (l >= 4) l -= l % 4;         // a multiple of the wave count: the stages then run wave-private (no workgroup barriers)
     return (int)(l < 1 ? 1 : l);
 }
 int cols_per_group(const Plan1D &pl, int cols) {
