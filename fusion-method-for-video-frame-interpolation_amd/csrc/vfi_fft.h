@@ -406,7 +406,7 @@ __device__ __forceinline__ void for_rows(int lines, int n, int pitch, LoadF load
         for (int q = 0; q < kChunk; ++q) {
             if (s0 + q < ns) {
                 const int l = (s0 + q) / qn, qq = (s0 + q) - l * qn, jq = kThreads * qq, j = t + jq;
-                if (j < n) use(l, j, jq, pt + (l * pitch + 264 * qq), v[q]);
+                if (j < n) use(l, j, jq, pt + (l * pitch + (kThreads + kThreads / 32) * qq), v[q]);
             }
         }
     }

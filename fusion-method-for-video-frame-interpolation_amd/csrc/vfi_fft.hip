@@ -42,7 +42,7 @@ void host_fft_pow2(std::vector<cd> &a) {       // in-place radix-2, forward, dou
 }
 
 template <int LOAD, int STORE, bool INV>
-__global__ __launch_bounds__(kThreads, 2) void fft_rows_kernel(const RowArgs a) {
+__global__ __launch_bounds__(kThreads, kThreads / 128) void fft_rows_kernel(const RowArgs a) {
     extern __shared__ float2 buf[];
     const int n = a.pl.n, m = a.pl.m, pitch = padded_length(m), tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * a.lines;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft_rows_kernel(const RowArgs a) 
 }
 
 template <bool INV>
-__global__ __launch_bounds__(kThreads, 2) void fft_cols_kernel(const ColArgs a) {
+__global__ __launch_bounds__(kThreads, kThreads / 128) void fft_cols_kernel(const ColArgs a) {
     extern __shared__ float2 buf[];
     const int h = a.pl.n, m = a.pl.m, tid = threadIdx.x, C = a.tile;
     const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);

@@ -427,7 +427,7 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles) {
 }
 
 template <bool FIRST, int NB>
-__global__ __launch_bounds__(kThreads, 2) void pyr_level_cols_kernel(const LevelColsArgs a) {
+__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_level_cols_kernel(const LevelColsArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
     const int h = a.h, w = a.w, m = a.ph.m, tid = threadIdx.x, C = a.tile, n = blockIdx.y;
@@ -593,7 +593,7 @@ __device__ __forceinline__ void zero_row_padding(float2 *buf, int lines, int pit
 
 // rows of T -> inverse row FFT -> (phase, amplitude) or the complex coefficient (coeff_to_values, src/train/pyramid.py:63-69)
 template <int NB>
-__global__ __launch_bounds__(kThreads, 2) void pyr_rows_polar_kernel(const RowsPolarArgs a) {
+__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_polar_kernel(const RowsPolarArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
     const int w = a.pw.n, m = a.pw.m, pitch = padded_length(m);
@@ -677,7 +677,7 @@ __global__ void pyr_amp_max_finish_kernel(const unsigned *__restrict__ bits, flo
 // (phase, amplitude) rows -> complex -> forward row FFT -> T (values_to_coeff, src/train/pyramid.py:99-107, + the row half of
 // reconstruct's fft2)
 template <int NB>
-__global__ __launch_bounds__(kThreads, 2) void pyr_rows_from_polar_kernel(const RowsPolarArgs a) {
+__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_from_polar_kernel(const RowsPolarArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
     const int w = a.pw.n, m = a.pw.m, pitch = padded_length(m);
@@ -748,7 +748,7 @@ struct CombineColsArgs {
 
 // cur = sum_b (-i) * FFTcol(T_b) * P_s[b]  +  embed(res * lomask)     (reconstruct: orientdft + resdft)
 template <int NB>
-__global__ __launch_bounds__(kThreads, 2) void pyr_combine_cols_kernel(const CombineColsArgs a) {
+__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_combine_cols_kernel(const CombineColsArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
     const int h = a.h, w = a.w, m = a.ph.m, tid = threadIdx.x, C = a.tile, n = blockIdx.y;

@@ -52,7 +52,7 @@ static void build(HostPlan &hp, int n) {
 template <int R, bool MULB>
 static void host_stage(float2 *buf, int lines, int pitch, int m, int p, const float2 *tw, int tw_len, const float2 *bfilt, int wave) {
     std::vector<StageRegs<R>> regs(kThreads);
-    const int t0 = wave < 0 ? 0 : 64 * wave, t1 = wave < 0 ? kThreads : 64 * wave + 64;
+    const int t0 = wave < 0 ? 0 : 64 * wave, t1 = wave < 0 ? kThreads : 64 * wave + 64;   // (kThreads / 64 waves)
     for (int t = t0; t < t1; ++t) stage_gather<R, MULB>(regs[t], wave < 0 ? team_all(t, lines) : team_wave(t, lines), buf, pitch, m, p, tw, tw_len, bfilt);
     for (int t = t0; t < t1; ++t) stage_scatter<R>(regs[t], wave < 0 ? team_all(t, lines) : team_wave(t, lines), buf, pitch, m, p);
 }
@@ -79,7 +79,7 @@ static void host_fft_team(float2 *buf, int lines, int pitch, const Plan1D &pl, i
     for (int s = 1; s < pl.nstages; ++s) { host_stage_any<false>(pl.radix[s], buf, lines, pitch, pl.m, p, pl.tw, pl.tw_len, nullptr, wave); p *= pl.radix[s]; }
 }
 static void host_fft(float2 *buf, int lines, int pitch, const Plan1D &pl) {
-    if (lines % 4 == 0) { for (int w = 0; w < 4; ++w) host_fft_team(buf, lines, pitch, pl, w); }
+    if (lines % (kThreads / 64) == 0) { for (int w = 0; w < kThreads / 64; ++w) host_fft_team(buf, lines, pitch, pl, w); }
     else host_fft_team(buf, lines, pitch, pl, -1);
 }
 
