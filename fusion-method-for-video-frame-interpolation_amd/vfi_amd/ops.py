@@ -122,6 +122,10 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2
             label = (f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}"
                      + (",ups>" if upsample2x else ">"))
             work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w, label)
+            if pc.ks == 1:
+                # a 1x1 layer (PhaseNet's 64 -> 8 prediction maps, the coarse 1x1 blocks, FusionNet's 32 -> 3 tail) does
+                # 2*Cout flop per input byte: it is bound by reading the input once, not by the matrix cores
+                work = ("byte", 4.0 * n * (cin + pc.cout) * h * w, label)
     _lib.call("vfi_conv2d_upsample2x" if upsample2x else "vfi_conv2d", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), rp, rs, yp, ys,
               n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], ws.data_ptr(), ws.numel(), _lib.stream_ptr(), work=work)
     return out
