@@ -31,6 +31,7 @@ constexpr int kThreads = 256;
 constexpr int kMaxElems = 8704;      // complex values of all lines of one workgroup (8 columns of a 1080-row level)
 constexpr int kMaxElemsB = 8192;     // ... when the plan is a Bluestein plan (its spectral product needs more registers)
 constexpr int kLdsElems = 9600;      // LDS elements incl. padding and the twiddle table (75 KiB: two workgroups per CU)
+constexpr int kLdsElemsMax = 11264;  // ... for a single line that does not fit the budget above (Bluestein on 8192 points: 4K frames)
 constexpr int kMaxStages = 8;
 
 struct Plan1D {                      // plain data, passed to kernels by value
@@ -508,8 +509,17 @@ inline bool factor_smooth(int n, int *radix, int *nstages) {
             radix[ns++] = r;
             m /= r;
         }
+    if (ns >= 2 && radix[ns - 1] == 2)          // (..., 16, 2) -> (..., 8, 4): no stage with T = m/2 butterflies per line
+        for (int i = ns - 2; i >= 0; --i)       // (its twiddle index range would exceed a quarter table)
+            if (radix[i] == 16) { radix[i] = 8; radix[ns - 1] = 4; break; }
     *nstages = ns;
     return m == 1 && n >= 2;
+}
+// entries of the LDS twiddle table a plan needs at least: every stage reads W^e for e < m / R
+inline int min_twiddle_entries(const Plan1D &pl) {
+    int need = 1;
+    for (int s = 1; s < pl.nstages; ++s) need = pl.m / pl.radix[s] > need ? pl.m / pl.radix[s] : need;
+    return need;
 }
 inline int bluestein_length(int n) {
     int M = 1;
@@ -526,6 +536,7 @@ inline int twiddle_entries(int m) { return (m % 4 == 0 && m >= 2048) ? m / 4 : (
 // how many rows of this plan fit into one workgroup's buffer (lines + twiddle table <= kLdsElems)
 inline int max_lines(const Plan1D &pl) {
     const int a = max_elems(pl) / pl.m, b = (kLdsElems - pl.tw_len) / row_pitch(pl);
+    if (a >= 1 && b < 1 && row_pitch(pl) + 33 + pl.tw_len <= kLdsElemsMax) return 1;     // one workgroup per CU
     return a < b ? a : b;
 }
 // LDS bytes of a row / column pass (lines, the twiddle table, `extra` bytes of the caller's own)

@@ -160,7 +160,7 @@ void allow_lds(K kernel) {      // > 64 KiB of dynamic LDS needs the attribute, 
     bool &d = done[vfi::current_device()];
     if (!d) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(kLdsElems * sizeof(float2)));
+                                  (int)(kLdsElemsMax * sizeof(float2)));
         d = true;
     }
 }
@@ -183,6 +183,9 @@ int make_plan(int n, Plan1D *out, void (*own)(void *ctx, void *dev), void *ctx) 
     pl.tw_len = twiddle_entries(pl.m);
     if (pl.m > kMaxElems) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d needs %d LDS elements (max %d)", n, pl.m, kMaxElems);
     if (pl.bluestein && !factor_smooth(pl.m, pl.radix, &pl.nstages)) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d", n);
+    if (pl.tw_len < min_twiddle_entries(pl)) pl.tw_len = min_twiddle_entries(pl);
+    if (max_lines(pl) < 1)       // one line + its twiddle table must fit a workgroup's LDS budget (non-smooth lengths above 2048)
+        return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d (transformed as %d points) exceeds the LDS budget of the engine", n, pl.m);
     auto upload = [&](const std::vector<cd> &v, const float2 **dev) -> int {
         std::vector<float2> f(v.size());
         for (size_t i = 0; i < v.size(); ++i) f[i] = make_float2((float)v[i].real(), (float)v[i].imag());

@@ -838,7 +838,7 @@ void allow_big_lds(K kernel) {      // > 64 KiB of dynamic LDS needs the attribu
     bool &d = done[vfi::current_device()];
     if (!d) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(vfi::fft::kLdsElems * sizeof(float2) + 8192));
+                                  (int)(vfi::fft::kLdsElemsMax * sizeof(float2) + 8192));
         d = true;
     }
 }

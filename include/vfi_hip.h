@@ -251,6 +251,8 @@ enum {
     VFI_PYR_COMPLEX_COEFF = 2  /* bands are interleaved (re, im) coefficients instead of (phase, amplitude) */
 };
 
+/* Every level size must be transformable by the LDS FFT engine: any length with prime factors 2, 3, 5 up to 8704, any
+ * other length up to 4096 (frames up to 3840x2160 qualify; VFI_ERR_UNSUPPORTED otherwise). */
 int vfi_pyr_plan_create(int H, int W, int height, int nbands, double scale_factor, int max_images,
                         vfi_pyr_plan **out);
 int vfi_pyr_plan_destroy(vfi_pyr_plan *plan);

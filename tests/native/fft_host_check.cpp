@@ -24,8 +24,11 @@ static void build(HostPlan &hp, int n) {
     pl.m = pl.bluestein ? bluestein_length(n) : n;
     pl.tw_len = twiddle_entries(pl.m);
     if (pl.bluestein && !factor_smooth(pl.m, pl.radix, &pl.nstages)) { std::printf("plan failed for %d\n", n); std::exit(2); }
+    if (pl.tw_len < min_twiddle_entries(pl)) pl.tw_len = min_twiddle_entries(pl);
     hp.tw.resize(pl.m);
     for (int k = 0; k < pl.m; ++k) hp.tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / pl.m), (float)std::sin(-2.0 * M_PI * k / pl.m));
+    // the device keeps only the first tw_len entries (in LDS): poison the rest so that a read beyond them shows
+    for (int k = pl.tw_len; k < pl.m; ++k) hp.tw[k] = make_float2(NAN, NAN);
     pl.tw = hp.tw.data();
     if (pl.bluestein) {
         std::vector<cd> w(n), b(pl.m, cd(0, 0)), B(pl.m);
@@ -128,7 +131,7 @@ static double check(int n, int lines, bool inv) {
 int main() {
     const int sizes[] = {2, 3, 4, 5, 6, 8, 9, 11, 12, 15, 16, 17, 22, 24, 30, 32, 43, 48, 60, 64, 65, 68, 77, 85, 90, 96, 120, 128,
                          135, 170, 182, 191, 240, 256, 270, 340, 382, 480, 512, 540, 679, 720, 764, 905, 960, 1024, 1080, 1280,
-                         1358, 1920, 2048, 4096};
+                         1358, 1920, 2048, 2716, 4096, 8192};
     int bad = 0;
     for (int n : sizes)
         for (int inv = 0; inv < 2; ++inv) {

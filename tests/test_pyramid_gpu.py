@@ -181,3 +181,17 @@ def test_amplitude_maxima_come_with_the_bands(device):
     plain, _ = pyr.filter(img, concat_frames=2, phase_scale=1.0 / math.pi)
     for a, b in zip(vals.amplitude, plain.amplitude):
         assert torch.equal(a, b)
+
+
+def test_round_trip_4k_levels_with_8192_point_bluestein(device):
+    # 3840x2160: level 1 is 1528 x 2716 = 4*7*97 wide -> Bluestein on 8192 points, one line per workgroup (the largest
+    # transform the LDS engine takes); one image, reconstruction only
+    h, w = 2160, 3840
+    height = layout_cpu.calc_pyr_height(h, w)
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand((1, h, w), generator=g).to(device)
+    pyr = Pyramid(height, 4, S2, device)
+    vals = pyr.filter(img)
+    assert tuple(vals.phase[1].shape[2:]) == (1528, 2716)
+    rec = pyr.inv_filter(vals)
+    assert _psnr(rec.cpu(), img.cpu()) >= 90.0
