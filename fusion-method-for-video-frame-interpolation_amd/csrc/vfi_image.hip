@@ -189,48 +189,97 @@ __global__ __launch_bounds__(256) void median_kernel(const float *__restrict__ x
 
 // ---- exact median, rank-transform + sliding bitset (the fast path, used whenever the tile fits) -------------------
 // A 16-column x 64-row output tile and its (16+S-1) x (64+S-1) input window (<= 8192 keys):
-//   1. the window's keys are sorted ONCE (bitonic sort of (key, position) pairs in LDS, 256 threads) and every
-//      position is replaced by its rank, a unique integer < 8192;
+//   1. the window's keys are sorted ONCE and every position is replaced by its rank, a unique integer < 8192.  The
+//      sort is a bitonic network over (key, position) pairs held in REGISTERS, 32 per thread: compare distances below
+//      32 stay inside a thread (55 of the 91 stages), distances 32..1024 are lane exchanges inside a wave (33 stages,
+//      ds_bpermute), only distances 2048 / 4096 (3 stages) go through LDS and a barrier;
 //   2. one thread per output row keeps the set of ranks inside its SxS window as a bitset; sliding the window one
 //      column clears S bits and sets S bits (LDS atomics, no return value) and nudges a (word, popcount-below)
 //      cursor to the median rank -- ~2*S LDS operations per output pixel instead of ~20 sweeps of S*S keys;
 //   3. the median is the sorted key at that rank: an element of the window, bit-exact with scipy.
-constexpr int kRkTW = 16, kRkTH = 64, kRkN = 8192, kRkWords = kRkN / 32;
+constexpr int kRkTW = 16, kRkTH = 64, kRkN = 8192, kRkWords = kRkN / 32, kRkPer = kRkN / 256;
+constexpr size_t kRkKeyBytes = (size_t)(kRkN + kRkN / 32) * 4;      // sorted keys at index e + e/32 (conflict-free column writes)
+constexpr size_t kRkLds = kRkKeyBytes + (size_t)kRkN * 2 + (size_t)kRkTH * kRkWords * 4;
+static_assert(kRkLds >= (size_t)kRkN * 8, "the cross-wave exchange buffer aliases the arrays of the later phases");
+
+typedef unsigned long long med_pair;     // key << 32 | position: unique, so the order is total
+
+__device__ __forceinline__ void med_cmpex(med_pair &a, med_pair &b, bool asc) {      // a is the lower index of the pair
+    const bool sw = (a > b) == asc;
+    const med_pair lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
 
 __global__ __launch_bounds__(256) void median_rank_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, int S) {
     extern __shared__ unsigned smem[];
-    unsigned *K = smem;                                              // [8192] keys, sorted in place
-    unsigned short *I = reinterpret_cast<unsigned short *>(K + kRkN);   // [8192] original position of each sorted key
-    unsigned short *R = I + kRkN;                                    // [8192] rank of each position
-    unsigned *B = reinterpret_cast<unsigned *>(R + kRkN);            // [64][256] one bitset per output row
+    unsigned *K = smem;                                                                  // sorted keys
+    unsigned short *R = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(smem) + kRkKeyBytes);   // [8192] rank of each position
+    unsigned *B = reinterpret_cast<unsigned *>(R + kRkN);                                // [64][256] one bitset per output row
+    med_pair *X = reinterpret_cast<med_pair *>(smem);                                   // [32][256] exchange (sort phase only)
     const int PW = kRkTW + S - 1, PH = kRkTH + S - 1, U = PW * PH;
     const int n = blockIdx.z, x0 = blockIdx.x * kRkTW, y0 = blockIdx.y * kRkTH, lo_off = S / 2;
     const float *p = x + (size_t)n * H * W;
     const int tid = threadIdx.x;
-    for (int e = tid; e < kRkN; e += 256) {
-        unsigned k = 0xffffffffu;
-        if (e < U) {
-            const int r = e / PW, c = e % PW;
-            k = key_of(p[(size_t)sym_reflect(y0 - lo_off + r, H) * W + sym_reflect(x0 - lo_off + c, W)]);
+    // element r of thread t sits at index i = 32 t + r of the network; which window position starts there is irrelevant
+    med_pair e[kRkPer];
+#pragma unroll
+    for (int r = 0; r < kRkPer; ++r) {
+        const int pos = r * 256 + tid;
+        unsigned k = 0xffffffffu;                            // padding sorts last: ranks >= U unused
+        if (pos < U) {
+            const int rr = pos / PW, cc = pos - rr * PW;
+            k = key_of(p[(size_t)sym_reflect(y0 - lo_off + rr, H) * W + sym_reflect(x0 - lo_off + cc, W)]);
         }
-        K[e] = k;
-        I[e] = (unsigned short)e;
+        e[r] = ((med_pair)k << 32) | (unsigned)pos;
     }
-    for (int e = tid; e < kRkTH * kRkWords; e += 256) B[e] = 0u;
-    __syncthreads();
-    for (int k = 2; k <= kRkN; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < kRkN / 2; t += 256) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                const unsigned a = K[i], b = K[l];
-                if ((a > b) == ((i & k) == 0)) {
-                    K[i] = b; K[l] = a;
-                    const unsigned short ia = I[i]; I[i] = I[l]; I[l] = ia;
+    // k = 2 .. 32: inside the thread
+#pragma unroll
+    for (int k = 2; k <= kRkPer; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int r = 0; r < kRkPer; ++r)
+                if ((r & j) == 0) med_cmpex(e[r], e[r | j], (((tid << 5) | r) & k) == 0);
+    // k = 64 .. 8192: partner threads first (distance j = 32 m, thread t ^ m), then the in-thread tail
+    for (int k = 2 * kRkPer; k <= kRkN; k <<= 1) {
+        const bool asc = ((tid << 5) & k) == 0;
+        for (int j = k >> 1; j >= kRkPer; j >>= 1) {
+            const int m = j >> 5;
+            const bool keep_min = ((tid & m) == 0) == asc;      // the lower index of an ascending pair keeps the minimum
+            if (m >= 64) {                                       // partner in another wave
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kRkPer; ++r) X[r * 256 + tid] = e[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kRkPer; ++r) {
+                    const med_pair o = X[r * 256 + (tid ^ m)];
+                    e[r] = (o < e[r]) == keep_min ? o : e[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < kRkPer; ++r) {
+                    const med_pair o = __shfl_xor(e[r], m, 64);
+                    e[r] = (o < e[r]) == keep_min ? o : e[r];
                 }
             }
-            __syncthreads();
         }
-    for (int e = tid; e < kRkN; e += 256) R[I[e]] = (unsigned short)e;   // padding (key 0xffffffff) sorts last: ranks >= U unused
+#pragma unroll
+        for (int j = kRkPer >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int r = 0; r < kRkPer; ++r)
+                if ((r & j) == 0) med_cmpex(e[r], e[r | j], asc);
+    }
+    __syncthreads();                                         // the exchange buffer is dead: its space becomes K, R, B
+#pragma unroll
+    for (int r = 0; r < kRkPer; ++r) {
+        const int i = (tid << 5) | r;
+        K[i + tid] = (unsigned)(e[r] >> 32);                 // index i + i/32
+        const unsigned pos = (unsigned)e[r];
+        if (pos < (unsigned)U) R[pos] = (unsigned short)i;
+    }
+    for (int w = tid; w < kRkTH * kRkWords; w += 256) B[w] = 0u;
     __syncthreads();
     if (tid < kRkTH) {
         unsigned *bits = B + tid * kRkWords;
@@ -258,7 +307,7 @@ __global__ __launch_bounds__(256) void median_rank_kernel(const float *__restric
             for (int i = need - below; i > 1; --i) wv &= wv - 1;      // drop the (need-below-1) lowest set bits
             const int rank = ptr * 32 + __ffs(wv) - 1;
             const int gx = x0 + tx;
-            if (gx < W && gy < H) y[(size_t)n * H * W + (size_t)gy * W + gx] = float_of(K[rank]);
+            if (gx < W && gy < H) y[(size_t)n * H * W + (size_t)gy * W + gx] = float_of(K[rank + (rank >> 5)]);
         }
     }
 }
@@ -433,7 +482,7 @@ extern "C" int vfi_median_filter(const float *x, float *y, int N, int H, int W, 
     VFI_REQUIRE(size <= 64, VFI_ERR_UNSUPPORTED, "vfi_median_filter: size %d > 64", size);
     VFI_REQUIRE(N <= 65535, VFI_ERR_UNSUPPORTED, "vfi_median_filter: batch");
     if ((kRkTW + size - 1) * (kRkTH + size - 1) <= kRkN && size >= 2) {
-        constexpr size_t lds = kRkN * 4 + kRkN * 2 * 2 + (size_t)kRkTH * kRkWords * 4;   // 128 KiB
+        constexpr size_t lds = kRkLds;   // 113 KiB
         static bool attr_done_dev[vfi::kMaxDevices] = {};  // per device, idempotent
         bool &attr_done = attr_done_dev[vfi::current_device()];
         if (!attr_done) {
