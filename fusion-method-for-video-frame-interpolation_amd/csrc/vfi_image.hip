@@ -193,9 +193,10 @@ __global__ __launch_bounds__(256) void median_kernel(const float *__restrict__ x
 //      sort is a bitonic network over (key, position) pairs held in REGISTERS, 32 per thread: compare distances below
 //      32 stay inside a thread (55 of the 91 stages), distances 32..1024 are lane exchanges inside a wave (33 stages,
 //      ds_bpermute), only distances 2048 / 4096 (3 stages) go through LDS and a barrier;
-//   2. one thread per output row keeps the set of ranks inside its SxS window as a bitset; sliding the window one
-//      column clears S bits and sets S bits (LDS atomics, no return value) and nudges a (word, popcount-below)
-//      cursor to the median rank -- ~2*S LDS operations per output pixel instead of ~20 sweeps of S*S keys;
+//   2. every output row keeps the set of ranks inside its SxS window as a bitset (four lanes per row share the
+//      work); sliding the window one column clears S bits and sets S bits (LDS atomics, no return value) and nudges
+//      a (word, popcount-below) cursor to the median rank -- ~2*S LDS operations per output pixel instead of ~20
+//      sweeps of S*S keys;
 //   3. the median is the sorted key at that rank: an element of the window, bit-exact with scipy.
 constexpr int kRkTW = 16, kRkTH = 64, kRkN = 8192, kRkWords = kRkN / 32, kRkPer = kRkN / 256;
 constexpr size_t kRkKeyBytes = (size_t)(kRkN + kRkN / 32) * 4;      // sorted keys at index e + e/32 (conflict-free column writes)
@@ -281,25 +282,39 @@ __global__ __launch_bounds__(256) void median_rank_kernel(const float *__restric
     }
     for (int w = tid; w < kRkTH * kRkWords; w += 256) B[w] = 0u;
     __syncthreads();
-    if (tid < kRkTH) {
-        unsigned *bits = B + tid * kRkWords;
-        const unsigned short *rows = R + tid * PW;      // window of output row `tid` starts at union row `tid`
+    // Four adjacent lanes share an output row: they split the insertions / removals (the LDS serves one wave's
+    // operations in order, so every lane's later reads see all four lanes' earlier atomics) and each keeps the cursor.
+    {
+        const int row = tid >> 2, q = tid & 3;
+        unsigned *bits = B + row * kRkWords;
+        const unsigned short *rows = R + row * PW;      // window of output row `row` starts at union row `row`
         const int need = (S * S) / 2 + 1;
-        for (int r = 0; r < S; ++r)
-            for (int c = 0; c < S; ++c) {
+        {
+            int r = 0, c = q;
+            while (c >= S) { c -= S; ++r; }
+#pragma unroll 8
+            for (int i = q; i < S * S; i += 4) {
                 const unsigned rk = rows[r * PW + c];
                 atomicOr(&bits[rk >> 5], 1u << (rk & 31));
+                c += 4;
+                while (c >= S) { c -= S; ++r; }
             }
+        }
         int ptr = 0, below = 0;
-        const int gy = y0 + tid;
+        const int gy = y0 + row;
         for (int tx = 0; tx < kRkTW; ++tx) {
             if (tx > 0) {
-                for (int r = 0; r < S; ++r) {
+                int delta = 0;
+#pragma unroll 4
+                for (int r = q; r < S; r += 4) {
                     const unsigned out = rows[r * PW + tx - 1], in = rows[r * PW + tx + S - 1];
                     atomicAnd(&bits[out >> 5], ~(1u << (out & 31)));
                     atomicOr(&bits[in >> 5], 1u << (in & 31));
-                    below += ((int)(in >> 5) < ptr) - ((int)(out >> 5) < ptr);
+                    delta += ((int)(in >> 5) < ptr) - ((int)(out >> 5) < ptr);
                 }
+                delta += __shfl_xor(delta, 1, 64);
+                delta += __shfl_xor(delta, 2, 64);
+                below += delta;
             }
             while (below >= need) { --ptr; below -= __popc(bits[ptr]); }
             unsigned wv = bits[ptr];
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256) void median_rank_kernel(const float *__restric
             for (int i = need - below; i > 1; --i) wv &= wv - 1;      // drop the (need-below-1) lowest set bits
             const int rank = ptr * 32 + __ffs(wv) - 1;
             const int gx = x0 + tx;
-            if (gx < W && gy < H) y[(size_t)n * H * W + (size_t)gy * W + gx] = float_of(K[rank + (rank >> 5)]);
+            if (q == (tx & 3) && gx < W && gy < H) y[(size_t)n * H * W + (size_t)gy * W + gx] = float_of(K[rank + (rank >> 5)]);
         }
     }
 }
