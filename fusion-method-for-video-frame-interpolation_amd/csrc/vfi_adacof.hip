@@ -225,80 +225,80 @@ __global__ __launch_bounds__(256, MIN_WAVES) void adacof_fused_kernel(
 
     float res[2][VEC][C];
     float var[2][VEC];
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const float *__restrict__ in = (side ? frame2 : frame0) + (size_t)n * (RGBX ? 4 : C) * plane;
-        const float *__restrict__ wp = side ? w2 : w1;
-        const float *__restrict__ ap = side ? a2 : a1;
-        const float *__restrict__ bp = side ? b2 : b1;
-        float s[VEC], pa[VEC], pb[VEC], mx[VEC];
-        FlowStats sa[VEC], sb[VEC];
+    // per-side running state
+    float acc[VEC][C], s[VEC], pa[VEC], pb[VEC], mx[VEC];
+    FlowStats sa[VEC], sb[VEC];
+    auto side_begin = [&](const Vec<VEC> &a0, const Vec<VEC> &b0) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) res[side][v][c] = 0.0f;
+            for (int c = 0; c < C; ++c) acc[v][c] = 0.0f;
             s[v] = 0.0f;
             mx[v] = -INFINITY;
             sa[v] = {0.0f, 0.0f};
             sb[v] = {0.0f, 0.0f};
+            pa[v] = a0.v[v];      // pivot = offsets of tap 0 (keeps the second moments well conditioned)
+            pb[v] = b0.v[v];
         }
-        {
-            Vec<VEC> a, b;  // pivot = offsets of tap 0 (keeps the second moments well conditioned)
-            a.load(ap + tbase);
-            b.load(bp + tbase);
+    };
+    auto tap = [&](int side, const float *__restrict__ in, int k, int l, Vec<VEC> w, const Vec<VEC> &a, const Vec<VEC> &b) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) { pa[v] = a.v[v]; pb[v] = b.v[v]; }
-        }
-        // one row of taps (F loads of w, alpha, beta each) in flight per iteration; a full F*F unroll
-        // exceeds the register file (spills) -- keep the row loop rolled
-#pragma unroll 1
-        for (int k = 0; k < F; ++k) {
-#pragma unroll UNROLL_L
-            for (int l = 0; l < F; ++l) {
-                const size_t t = tbase + (size_t)(k * F + l) * plane;
-                Vec<VEC> w, a, b;
-                w.load(wp + t);
-                a.load(ap + t);
-                b.load(bp + t);
+        for (int v = 0; v < VEC; ++v) {
+            if constexpr (SOFTMAX) {   // w = exp(logit - running max)
+                if constexpr (FT > 0) {
+                    w.v[v] = expf(w.v[v] - mx[v]);      // (the row's maximum is already folded into mx: raise_max)
+                } else {                                // rescale what was accumulated so far
+                    const float mnew = fmaxf(mx[v], w.v[v]);
+                    const float sc = expf(mx[v] - mnew);
+                    w.v[v] = expf(w.v[v] - mnew);
+                    mx[v] = mnew;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    if constexpr (SOFTMAX) {   // w = exp(logit - running max); rescale what was accumulated so far
-                        const float mnew = fmaxf(mx[v], w.v[v]);
-                        const float sc = expf(mx[v] - mnew);
-                        w.v[v] = expf(w.v[v] - mnew);
-                        mx[v] = mnew;
-#pragma unroll
-                        for (int c = 0; c < C; ++c) res[side][v][c] *= sc;
-                        s[v] *= sc;
-                        sa[v].m *= sc; sa[v].q *= sc; sb[v].m *= sc; sb[v].q *= sc;
-                    }
-                    if constexpr (WIN)
-                        tap_accumulate_win(win_lds + side * WH * WW, WH, WW, yb, xb, reinterpret_cast<const float4 *>(in), H, W,
-                                           y + k * dil - pad, x0 + v + l * dil - pad, w.v[v], a.v[v], b.v[v], res[side][v]);
-                    else if constexpr (RGBX)
-                        tap_accumulate_rgbx(reinterpret_cast<const float4 *>(in), H, W, y + k * dil - pad,
-                                            x0 + v + l * dil - pad, w.v[v], a.v[v], b.v[v], res[side][v]);
-                    else
-                        tap_accumulate<C>(in, plane, H, W, y + k * dil - pad, x0 + v + l * dil - pad,
-                                          w.v[v], a.v[v], b.v[v], res[side][v]);
-                    const float da = a.v[v] - pa[v], db = b.v[v] - pb[v];
-                    s[v] += w.v[v];
-                    sa[v].m += w.v[v] * da;
-                    sa[v].q += w.v[v] * da * da;
-                    sb[v].m += w.v[v] * db;
-                    sb[v].q += w.v[v] * db * db;
+                    for (int c = 0; c < C; ++c) acc[v][c] *= sc;
+                    s[v] *= sc;
+                    sa[v].m *= sc; sa[v].q *= sc; sb[v].m *= sc; sb[v].q *= sc;
                 }
             }
+            if constexpr (WIN)
+                tap_accumulate_win(win_lds + side * WH * WW, WH, WW, yb, xb, reinterpret_cast<const float4 *>(in), H, W,
+                                   y + k * dil - pad, x0 + v + l * dil - pad, w.v[v], a.v[v], b.v[v], acc[v]);
+            else if constexpr (RGBX)
+                tap_accumulate_rgbx(reinterpret_cast<const float4 *>(in), H, W, y + k * dil - pad,
+                                    x0 + v + l * dil - pad, w.v[v], a.v[v], b.v[v], acc[v]);
+            else
+                tap_accumulate<C>(in, plane, H, W, y + k * dil - pad, x0 + v + l * dil - pad,
+                                  w.v[v], a.v[v], b.v[v], acc[v]);
+            const float da = a.v[v] - pa[v], db = b.v[v] - pb[v];
+            s[v] += w.v[v];
+            sa[v].m += w.v[v] * da;
+            sa[v].q += w.v[v] * da * da;
+            sb[v].m += w.v[v] * db;
+            sb[v].q += w.v[v] * db * db;
         }
-        // Var = sum_k W (Mean - x)^2 with Mean = sum_k W x   (fusion_adacofnet.py:204-208),
-        // evaluated from moments pivoted at x_p: x = x' + x_p, c = x_p (S - 1):
-        //   Var = M'^2 (S - 2) + Q' + 2 c M' (S - 1) + c^2 S
+    };
+    // online softmax, one step per ROW of taps: the running maximum takes in the row's F logits at once and what was
+    // accumulated so far is rescaled once (F + 1 exponentials per row instead of 2 F)
+    auto raise_max = [&](const float (&row_max)[VEC]) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float mnew = fmaxf(mx[v], row_max[v]);
+            const float sc = expf(mx[v] - mnew);
+            mx[v] = mnew;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[v][c] *= sc;
+            s[v] *= sc;
+            sa[v].m *= sc; sa[v].q *= sc; sb[v].m *= sc; sb[v].q *= sc;
+        }
+    };
+    // Var = sum_k W (Mean - x)^2 with Mean = sum_k W x   (fusion_adacofnet.py:204-208),
+    // evaluated from moments pivoted at x_p: x = x' + x_p, c = x_p (S - 1):
+    //   Var = M'^2 (S - 2) + Q' + 2 c M' (S - 1) + c^2 S
+    auto side_end = [&](float (&r)[VEC][C], float (&vr)[VEC]) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             if constexpr (SOFTMAX) {   // normalise: every accumulated sum is linear in the weights
                 const float inv = 1.0f / s[v];
 #pragma unroll
-                for (int c = 0; c < C; ++c) res[side][v][c] *= inv;
+                for (int c = 0; c < C; ++c) acc[v][c] *= inv;
                 sa[v].m *= inv; sa[v].q *= inv; sb[v].m *= inv; sb[v].q *= inv;
                 s[v] = 1.0f;
             }
@@ -306,7 +306,80 @@ __global__ __launch_bounds__(256, MIN_WAVES) void adacof_fused_kernel(
             const float ca = pa[v] * (S - 1.0f), cb = pb[v] * (S - 1.0f);
             const float va = sa[v].m * sa[v].m * (S - 2.0f) + sa[v].q + 2.0f * ca * sa[v].m * (S - 1.0f) + ca * ca * S;
             const float vb = sb[v].m * sb[v].m * (S - 2.0f) + sb[v].q + 2.0f * cb * sb[v].m * (S - 1.0f) + cb * cb * S;
-            var[side][v] = va + vb;
+            vr[v] = va + vb;
+#pragma unroll
+            for (int c = 0; c < C; ++c) r[v][c] = acc[v][c];
+        }
+    };
+    if constexpr (FT > 0) {
+        // The 2 F rows of taps (side 0, then side 2) as ONE pipeline: the F (w, alpha, beta) triples of the next row are
+        // requested before the current row's gathers and arithmetic start, so a wave always has loads in flight.
+        auto load_row = [&](int r, Vec<VEC> (&w)[FT], Vec<VEC> (&a)[FT], Vec<VEC> (&b)[FT]) {
+            const int side = r >= FT ? 1 : 0, k = r - side * FT;
+            const float *__restrict__ wp = side ? w2 : w1;
+            const float *__restrict__ ap = side ? a2 : a1;
+            const float *__restrict__ bp = side ? b2 : b1;
+#pragma unroll
+            for (int l = 0; l < FT; ++l) {
+                const size_t t = tbase + (size_t)(k * FT + l) * plane;
+                w[l].load(wp + t);
+                a[l].load(ap + t);
+                b[l].load(bp + t);
+            }
+        };
+        Vec<VEC> cw[FT], ca[FT], cb[FT];
+        load_row(0, cw, ca, cb);
+#pragma unroll 1
+        for (int r = 0; r < 2 * FT; ++r) {
+            Vec<VEC> nw[FT], na[FT], nb[FT];
+            load_row(r + 1 < 2 * FT ? r + 1 : r, nw, na, nb);      // (the last iteration re-requests its own row: no branch)
+            const int side = r >= FT ? 1 : 0, k = r - side * FT;
+            const float *__restrict__ in = (side ? frame2 : frame0) + (size_t)n * (RGBX ? 4 : C) * plane;
+            if (k == 0) side_begin(ca[0], cb[0]);
+            if constexpr (SOFTMAX) {
+                float row_max[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    row_max[v] = cw[0].v[v];
+#pragma unroll
+                    for (int l = 1; l < FT; ++l) row_max[v] = fmaxf(row_max[v], cw[l].v[v]);
+                }
+                raise_max(row_max);
+            }
+#pragma unroll
+            for (int l = 0; l < FT; ++l) tap(side, in, k, l, cw[l], ca[l], cb[l]);
+            if (k == FT - 1) {
+                if (side == 0) side_end(res[0], var[0]);
+                else side_end(res[1], var[1]);
+            }
+#pragma unroll
+            for (int l = 0; l < FT; ++l) { cw[l] = nw[l]; ca[l] = na[l]; cb[l] = nb[l]; }
+        }
+    } else {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const float *__restrict__ in = (side ? frame2 : frame0) + (size_t)n * (RGBX ? 4 : C) * plane;
+            const float *__restrict__ wp = side ? w2 : w1;
+            const float *__restrict__ ap = side ? a2 : a1;
+            const float *__restrict__ bp = side ? b2 : b1;
+            {
+                Vec<VEC> a, b;
+                a.load(ap + tbase);
+                b.load(bp + tbase);
+                side_begin(a, b);
+            }
+#pragma unroll 1
+            for (int k = 0; k < F; ++k)
+#pragma unroll UNROLL_L
+                for (int l = 0; l < F; ++l) {
+                    const size_t t = tbase + (size_t)(k * F + l) * plane;
+                    Vec<VEC> w, a, b;
+                    w.load(wp + t);
+                    a.load(ap + t);
+                    b.load(bp + t);
+                    tap(side, in, k, l, w, a, b);
+                }
+            side_end(res[side], var[side]);
         }
     }
 

@@ -159,6 +159,10 @@ def bench_adacof(dev):
     t = timeit(lambda: adacof_fused(x0, x2, W[0], a[0], a[1], W[1], a[2], a[3], occ, 1, True, True, rgbx=True))
     by = n * h * w * (150 * 4 + 4 + 24 + 36 + 4)
     print(f"adacof_fused_rgbx 1088x1920: {t*1e3:.3f} ms  {by/t/1e9:.0f} GB/s ({by/t/8e12*100:.1f}% of 8 TB/s)", flush=True)
+    L = torch.randn((2, n, 25, h, w), generator=g).to(dev)
+    t = timeit(lambda: adacof_fused(x0, x2, L[0], a[0], a[1], L[1], a[2], a[3], occ, 1, False, True, rgbx=True, weights_are_logits=True))
+    by = n * h * w * (150 * 4 + 4 + 24 + 12 + 4)
+    print(f"adacof_fused_rgbx logits, no sides (as the frame runs it): {t*1e3:.3f} ms  {by/t/1e9:.0f} GB/s ({by/t/8e12*100:.1f}% of 8 TB/s)", flush=True)
     for sides, mask in ((True, True), (False, False)):
         t = timeit(lambda: adacof_fused(f0, f2, W[0], a[0], a[1], W[1], a[2], a[3], occ, 1, sides, mask))
         by = n * h * w * (150 * 4 + 4 + 24 + 12 * (3 if sides else 1) + (4 if mask else 0))
