@@ -6,6 +6,25 @@
 namespace vfi {
 namespace conv {
 
+// Exact unsigned division by a run-time constant (Granlund-Montgomery, round-up variant): five scalar instructions
+// instead of the ~25 of a 32-bit division; exact for every 32-bit n.
+struct FastDiv {
+    unsigned m, sh1, sh2;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                  // ceil(log2 d)
+    FastDiv f;
+    f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ int fast_div(int n, const FastDiv &f) {
+    const unsigned t = __umulhi((unsigned)n, f.m);
+    return (int)((t + (((unsigned)n - t) >> f.sh1)) >> f.sh2);
+}
+
 struct ConvArgs {
     const float *x;      // (N, Cin, H, W) slice, batch stride x_bs
     const float *wp;     // packed weights [Cin_pad][KS*KS][Cout_pad]
@@ -23,6 +42,7 @@ struct ConvArgs {
     long long x2_bs;
     int rsz_channels;      // multiple of CK
     int wino_tiles, wino_items, wino_batch, wino_run;   // Winograd kernel: spatial tiles per sample; work items per K split; N; tiles per XCD run
+    FastDiv fd_items, fd_cb, fd_run, fd_tiles, fd_tiles_x, fd_splits;   // ... and their reciprocals (item decoding)
     int Hs, Ws;    // UPS kernels: size of the low-resolution source x (H = 2*Hs, W = 2*Ws)
     float ups_sy, ups_sx;   // (Hs-1)/(H-1), (Ws-1)/(W-1): torch bilinear, align_corners=True
     float *pool;            // Winograd kernel: optional second output, the 2x2 / stride-2 pooled result (N, Cout, H/2, W/2)

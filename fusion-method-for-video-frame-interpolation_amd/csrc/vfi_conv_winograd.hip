@@ -78,22 +78,25 @@ __device__ __forceinline__ Item decode_item(const ConvArgs &a, int L) {
     using T = WinoTile;
     Item it;
     const int cb = a.Cout_pad / T::BN;
-    it.split = L / a.wino_items;
+    it.split = fast_div(L, a.fd_items);
     const int Lr = L - it.split * a.wino_items;
     // XCD-aware order.  Workgroup L runs on XCD L % 8 (own L2 each).  Consecutive slots of one XCD take the channel
     // blocks of the SAME spatial tile, then the next tile of a run of `wino_run` horizontally adjacent tiles: the input
     // tile is fetched once for all channel blocks, and the 128-byte lines a tile shares with its left / right neighbours
     // (a tile is exactly one line wide, its halo touches both neighbouring lines) stay inside one L2 within a run
     // (fabric reads of the 1080p 64->64 layers: 3.4 -> 1.5 GB by FETCH_SIZE).  Runs are dealt round-robin to the XCDs.
+    // (run-time divisors through their precomputed reciprocals: the decoding runs once per item and wave, twice over)
     const int xcd = Lr & 7, q = Lr >> 3;
-    it.nb = q % cb;
-    const int tq = q / cb, run = a.wino_run;
-    const int tl = ((tq / run) * 8 + xcd) * run + tq % run;
-    it.n = tl / a.wino_tiles;
+    const int tq = fast_div(q, a.fd_cb), run = a.wino_run;
+    it.nb = q - tq * cb;
+    const int tr = fast_div(tq, a.fd_run);
+    const int tl = (tr * 8 + xcd) * run + (tq - tr * run);
+    it.n = fast_div(tl, a.fd_tiles);
     const int t = tl - it.n * a.wino_tiles;
     it.valid = it.n < a.wino_batch;
-    it.x0 = (t % a.tiles_x) * T::TW;
-    it.y0 = (t / a.tiles_x) * T::TH;
+    const int ty = fast_div(t, a.fd_tiles_x);
+    it.x0 = (t - ty * a.tiles_x) * T::TW;
+    it.y0 = ty * T::TH;
     return it;
 }
 
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
         ++iseq;
         ifirst = true;
         inb = it.nb;
-        const int ch0 = nchunks_all * it.split / a.splits;
-        ileft = nchunks_all * (it.split + 1) / a.splits - ch0;
+        const int ch0 = fast_div(nchunks_all * it.split, a.fd_splits);
+        ileft = fast_div(nchunks_all * (it.split + 1), a.fd_splits) - ch0;
         in_ptr = reinterpret_cast<const char *>(a.x + (size_t)it.n * a.x_bs) + (size_t)ch0 * in_chunk_bytes;
         in_bytes_left = (unsigned)(a.Cin - ch0 * T::CK) * (unsigned)HW * 4u;       // (host: Cin*H*W*4 < 2^32)
         w_ptr = reinterpret_cast<const char *>(a.wp) + (size_t)ch0 * w_chunk_bytes;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
         return;
     }
     Item it = decode_item(a, cL);
-    int ch = nchunks_all * it.split / a.splits, ch_end = nchunks_all * (it.split + 1) / a.splits;
+    int ch = fast_div(nchunks_all * it.split, a.fd_splits), ch_end = fast_div(nchunks_all * (it.split + 1), a.fd_splits);
     int slot = 0, cseq = 0;
     // The oldest chunk in flight has landed once no more than the DMA instructions of the younger chunks in flight are
     // outstanding (>= MIN_LOADS each; an item's stores in between only make the wait earlier).  The barrier makes every
@@ -425,8 +428,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs
             cL = nL;
             ++cseq;
             it = decode_item(a, cL);
-            ch = nchunks_all * it.split / a.splits;
-            ch_end = nchunks_all * (it.split + 1) / a.splits;
+            ch = fast_div(nchunks_all * it.split, a.fd_splits);
+            ch_end = fast_div(nchunks_all * (it.split + 1), a.fd_splits);
             zero_acc();
         }
     }
@@ -508,6 +511,12 @@ int vfi::conv::launch_winograd(const ConvArgs &a, int N, hipStream_t s) {
             if (nchunks / S >= 8 && out_floats * S <= a.ws_floats && cost(S) < cost(best)) best = S;
         if (cost(best) <= 0.9 * cost(1)) b.splits = best;
     }
+    b.fd_items = make_fastdiv((unsigned)b.wino_items);
+    b.fd_cb = make_fastdiv((unsigned)cb);
+    b.fd_run = make_fastdiv((unsigned)b.wino_run);
+    b.fd_tiles = make_fastdiv((unsigned)b.wino_tiles);
+    b.fd_tiles_x = make_fastdiv((unsigned)b.tiles_x);
+    b.fd_splits = make_fastdiv((unsigned)b.splits);
     const long long items = (long long)b.wino_items * b.splits;
     dim3 grid((unsigned)(items < resident ? items : resident));
     const int act = b.splits > 1 ? 0 : b.act;      // split-K: the reduce kernel applies bias / activation / residual

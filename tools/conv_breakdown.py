@@ -41,6 +41,6 @@ agg = _lib.PROFILE.summary()
 _lib.PROFILE = None
 tot = sum(v["seconds"] for v in agg.values())
 print(f"total {tot * 1e3:.2f} ms over {sum(v['calls'] for v in agg.values())} calls")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"])[:45]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"])[:400]:
     rate = v["work"] / v["seconds"] / 1e12 if v["kind"] == "flop" else v["work"] / v["seconds"] / 1e9
     print(f"{v['seconds'] * 1e3:8.3f} ms  x{v['calls']:3d}  {rate:8.1f} {'TF/s' if v['kind'] == 'flop' else 'GB/s'}  {k}")
