@@ -20,8 +20,8 @@ inline FastDiv make_fastdiv(unsigned d) {
     f.sh2 = l > 0 ? l - 1 : 0;
     return f;
 }
-__device__ __forceinline__ int fast_div(int n, const FastDiv &f) {
-    const unsigned t = __umulhi((unsigned)n, f.m);
+__host__ __device__ __forceinline__ int fast_div(int n, const FastDiv &f) {
+    const unsigned t = (unsigned)(((unsigned long long)(unsigned)n * f.m) >> 32);      // (one s_mul_hi_u32 / v_mul_hi_u32)
     return (int)((t + (((unsigned)n - t) >> f.sh1)) >> f.sh2);
 }
 
