@@ -199,6 +199,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, not steps: one untimed frame per in-flight slot creates that slot's pyramid plans / tables and (once) the
+    # packed weights, whatever --warmup says
+    for k in range(len(runners)):
+        step(k)
+    barrier()
     for i in range(args.warmup):
         step(i)
     barrier()

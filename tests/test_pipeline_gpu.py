@@ -84,9 +84,26 @@ def test_fused_frame_full_size_properties(h, w, device):
     assert m1.shape == (1, 1, h, w)
 
 
+def test_fused_frame_runs_at_4k(device):
+    # the largest frame the FFT engine's tables cover (8192-point Bluestein lines for the 1528 x 2716
+    # level): one fused frame end to end, size-independent properties only
+    h, w = 2160, 3840
+    run = _models(device, pipeline_cpu.seeded_weights(4))
+    g = torch.Generator().manual_seed(7)
+    f0 = torch.rand((3, h, w), generator=g).to(device)
+    f2 = (0.5 * f0 + 0.5 * torch.rand((3, h, w), generator=g).to(device)).contiguous()
+    out = run(f0, f2, output_baseline=True)
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    for k in ("final", "phase_pred", "baseline", "phase_uncertainty", "ada_uncertainty", "flow_var_map"):
+        assert out[k].min().item() >= 0.0 and out[k].max().item() <= 1.0, k
+    assert out["final"].shape == (1, 3, h, w)
+    assert (out["final"] - out["base"].clamp(0, 1)).abs().max().item() <= 1.0
+
+
 def test_frame_is_capturable_into_a_hip_graph(device):
-    # every library call only enqueues on its stream (no allocation / synchronisation inside): a whole frame,
-    # hipFFT included, can be captured into a hipGraph and replayed on new inputs with identical results
+    # every library call only enqueues on its stream (no allocation / synchronisation inside): a whole frame, the
+    # pyramid's FFT passes included, can be captured into a hipGraph and replayed on new inputs with identical results
     weights = pipeline_cpu.seeded_weights(3)
     run = _models(device, weights)
     a0, _, a2 = (torch.from_numpy(x).to(device) for x in synth.translating_pair(5, 64, 96))
