@@ -408,8 +408,9 @@ void vfi::conv::launch_splitk_reduce(const ConvArgs &b, int N, hipStream_t s) {
 
 extern "C" long long vfi_conv2d_packed_floats(int Cout, int Cin, int KS) {
     if (Cout <= 0 || Cin <= 0 || KS <= 0) return -1;
-    // 3x3: the direct layout [Cin_pad][9][Cout_pad] is followed by the Winograd layout [Cin_pad][4][Cout_pad][4]
-    return (long long)round_up(Cin, 8) * (KS * KS + (KS == 3 ? 16 : 0)) * round_up(Cout, 32);
+    // 3x3: the direct layout [Cin_pad][9][Cout_pad] is followed by the Winograd banks: F(2x2) [Cin_pad][4][Cout_pad][4]
+    // and F(4x4) [Cin_pad][9][Cout_pad][4]
+    return (long long)round_up(Cin, 8) * (KS * KS + (KS == 3 ? 16 + 36 : 0)) * round_up(Cout, 32);
 }
 
 extern "C" int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin,
@@ -422,7 +423,11 @@ extern "C" int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *p
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(conv2d_pack_kernel, dim3(blocks), dim3(256), 0, vfi::as_stream(stream), w_oihw, scale,
                        packed, Cout, Cin, KS * KS, Cin_pad, Cout_pad);
-    if (KS == 3) launch_pack_winograd(w_oihw, scale, packed + total, Cout, Cin, Cin_pad, Cout_pad, vfi::as_stream(stream));
+    if (KS == 3) {
+        launch_pack_winograd(w_oihw, scale, packed + total, Cout, Cin, Cin_pad, Cout_pad, vfi::as_stream(stream));
+        launch_pack_winograd4(w_oihw, scale, packed + total + (long long)Cin_pad * 16 * Cout_pad, Cout, Cin, Cin_pad, Cout_pad,
+                              vfi::as_stream(stream));
+    }
     return vfi::check_launch("vfi_conv2d_pack");
 }
 
@@ -482,8 +487,12 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     static const bool wino_on = !(getenv("VFI_CONV_WINOGRAD") && atoi(getenv("VFI_CONV_WINOGRAD")) == 0);
     const long long wino_work_items = (long long)a.tiles_x * vfi::ceil_div(H, 8) * N * (a.Cout_pad / 32) * 16;   // (x max. K split)
     if (KS == 3 && wino_on && (long long)Cin * H * W * 4 < (1ll << 32) && wino_work_items < (1ll << 30)) {
-        a.wp = packed_w + (size_t)a.Cin_pad * 9 * a.Cout_pad;
         a.pool = pooled; a.pool_bs = pooled_bstride;
+        if (winograd4_suits(a, N)) {        // plain, large layers: the F(4x4) tile
+            a.wp = packed_w + (size_t)a.Cin_pad * (9 + 16) * a.Cout_pad;
+            return launch_winograd4(a, N, s);
+        }
+        a.wp = packed_w + (size_t)a.Cin_pad * 9 * a.Cout_pad;
         return launch_winograd(a, N, s);
     }
     if (pooled) {       // not a Winograd layer: the convolution, then the pooling pass

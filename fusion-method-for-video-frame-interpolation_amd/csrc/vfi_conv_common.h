@@ -74,6 +74,11 @@ void launch_splitk_reduce(const ConvArgs &a, int N, hipStream_t s);
 int launch_winograd(const ConvArgs &a, int N, hipStream_t s);
 void launch_pack_winograd(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin, int Cin_pad, int Cout_pad,
                           hipStream_t s);
+// vfi_conv_winograd4.hip
+bool winograd4_suits(const ConvArgs &a, int N);
+int launch_winograd4(const ConvArgs &a, int N, hipStream_t s);
+void launch_pack_winograd4(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin, int Cin_pad, int Cout_pad,
+                           hipStream_t s);
 
 }  // namespace conv
 }  // namespace vfi

@@ -1,0 +1,459 @@
+// 3x3 convolutions (stride 1, "same" size, zero or reflect padding) with the larger Winograd tile F(4x4, 3x3) on the
+// gfx950 matrix cores (v_mfma_f32_16x16x4_f32): 36 multiply-adds per 4x4 outputs and channel pair instead of the 64 of
+// F(2x2, 3x3) (vfi_conv_winograd.hip), i.e. 1.78x fewer MFMAs, for plain layers (bias + activation, no residual, no
+// pooled output, no K split) that are large enough to fill the chip; everything else stays with the F(2x2) kernel.
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A     with the 6x6 transforms of the points {0, +-1, +-2, inf}
+//
+//   * one 512-thread workgroup per CU works on a 16-row x 64-column output tile (4 x 16 Winograd tiles) for 32 output
+//     channels: wave w owns tile row w & 3 and the 16-channel half w >> 2 (M = 16 channels, N = 16 tiles, K = 4 input
+//     channels per MFMA; the 36 frequency positions are 36 independent accumulators, 144 registers);
+//   * per K step a lane reads ONE raw 6x6 input patch (its tile, its channel: a 16-byte and an 8-byte LDS read per row),
+//     forms V = B^T d B in registers (12 one-dimensional transforms of 13 operations) and feeds V's 36 entries to 36
+//     MFMAs whose A operands are the pre-transformed weights U = G g G^T ([cin][group of 4 positions][cout][4] in LDS:
+//     one ds_read_b128 = four positions);
+//   * the 36 position accumulators of one (channel, tile) sit in one lane: the output transform is register-only and
+//     a lane stores its 4x4 block as four 16-byte row segments per channel (16 lanes = one 256-byte run per row);
+//   * staging is all LDS-DMA (buffer_load ... lds) as in the F(2x2) kernel: tile-invariant per-lane source offsets,
+//     chunk base and channel tail in the buffer descriptor, out-of-range offsets read as 0; interior tiles fetch 16
+//     bytes per lane (38 DMA instructions per workgroup and 4-channel chunk), tiles on the left / right image border per
+//     element (10 + 3); a ring of 4 buffers of 38 KiB (the weight slab of a chunk is 18 KiB: 36 positions x 32
+//     channels x 4) filled three chunks ahead, ONE barrier per chunk and a counted s_waitcnt vmcnt; the requests of a
+//     chunk are spread over the six rows of MFMAs of an earlier one (all eight waves of the CU run in step);
+//   * persistent workgroups walk the (tile, channel block) items in the XCD-aware order of the F(2x2) kernel.
+// Accuracy: the transforms' constants (up to 8 in A, 5 in B, 1/24 in G) cost about a decimal digit -- rms error 1.9e-6 of
+// the output rms against 2.7e-7 for F(2x2) (tools/probes/winograd_f43_error.py).
+#include "vfi_conv_common.h"
+
+#include <cstdlib>
+
+using namespace vfi::conv;
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct Wino4Tile {
+    static constexpr int TH = 16, TW = 64, R = TH + 2, CK = 4, BN = 32, THREADS = 512, WAVES = THREADS / 64;
+    static constexpr int ROWP = 68;                       // LDS row pitch: 66 columns fetched as 17 float4
+    static constexpr int ROW_PIECES = ROWP / 4;           // 17
+    static constexpr int PLANE = R * ROWP;                // 1224
+    // LDS stride of a channel plane = 0 (mod 64) dwords: the 16-byte patch reads of a 16-lane group (two channels,
+    // lanes 16 bytes apart) then cover the 64 banks exactly once
+    static constexpr int PLANE_S = (PLANE + 63) / 64 * 64;              // 1280
+    static constexpr int PIECES = PLANE_S / 4;            // float4 pieces per plane (320, 306 of them real)
+    static constexpr int IN_FLOATS = CK * PLANE_S;        // 5120 = 20 wave-instructions of 16 bytes per lane, 80 of 4 bytes
+    static constexpr int IN_WI = IN_FLOATS / 256;         // 16-byte DMA wave-instructions per chunk: wave w issues w, w+8, w+16 (< 20)
+    static constexpr int IN_X4 = (IN_WI + WAVES - 1) / WAVES;                       // 3 (waves 4..7: 2)
+    static constexpr int IN_X1 = IN_FLOATS / THREADS;     // 4-byte DMA instructions per wave (10)
+    static constexpr int NPOS = 36, NGRP = NPOS / 4;
+    static constexpr int W_FLOATS = CK * NPOS * BN;       // 4608 = 18 wave-instructions
+    static constexpr int W_WI = W_FLOATS / 256;
+    static constexpr int W_INSTR = (W_WI + WAVES - 1) / WAVES;                      // 3 (waves 2..7: 2)
+    static constexpr int BUF = IN_FLOATS + W_FLOATS;      // 38 KiB
+    static constexpr int NBUF = 4;
+    static constexpr int BIAS_SLOTS = 8;                  // (> NBUF: the DMA cursor runs up to NBUF one-chunk items ahead)
+    static constexpr int BIAS_OFF = NBUF * BUF;           // BIAS_SLOTS x 64 floats
+    static constexpr size_t LDS_BYTES = ((size_t)NBUF * BUF + BIAS_SLOTS * 64) * sizeof(float);
+    static_assert(IN_X1 * THREADS == IN_FLOATS && IN_FLOATS % 256 == 0 && W_FLOATS % 256 == 0 && PLANE_S % 64 == 0 && ROWP % 4 == 0 &&
+                      BIAS_SLOTS > NBUF && LDS_BYTES <= 160 * 1024 && IN_X4 == 3 && W_INSTR == 3, "tile layout");
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword data
+}
+// wave-uniform by construction; pinned to SGPRs (see vfi_conv_winograd.hip)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const char *uni(const char *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+}
+
+struct Item {
+    int n, x0, y0, nb;
+    bool valid;
+};
+
+// Same XCD-aware item order as the F(2x2) kernel (vfi_conv_winograd.hip: decode_item), one K split.
+__device__ __forceinline__ Item decode_item(const ConvArgs &a, int L) {
+    using T = Wino4Tile;
+    Item it;
+    const int cb = a.Cout_pad / T::BN;
+    const int xcd = L & 7, q = L >> 3;
+    const int tq = fast_div(q, a.fd_cb), run = a.wino_run;
+    it.nb = q - tq * cb;
+    const int tr = fast_div(tq, a.fd_run);
+    const int tl = (tr * 8 + xcd) * run + (tq - tr * run);
+    it.n = fast_div(tl, a.fd_tiles);
+    const int t = tl - it.n * a.wino_tiles;
+    it.valid = it.n < a.wino_batch;
+    const int ty = fast_div(t, a.fd_tiles_x);
+    it.x0 = (t - ty * a.tiles_x) * T::TW;
+    it.y0 = ty * T::TH;
+    return it;
+}
+
+// B^T x for the six samples of one line (13 operations)
+__device__ __forceinline__ void input_transform6(const float (&x)[6], float (&t)[6]) {
+    t[0] = fmaf(4.0f, x[0], fmaf(-5.0f, x[2], x[4]));
+    const float p = fmaf(-4.0f, x[2], x[4]), q = fmaf(-4.0f, x[1], x[3]);
+    t[1] = p + q;
+    t[2] = p - q;
+    const float r = x[4] - x[2], s = 2.0f * (x[3] - x[1]);
+    t[3] = r + s;
+    t[4] = r - s;
+    t[5] = fmaf(4.0f, x[1], fmaf(-5.0f, x[3], x[5]));
+}
+// A^T m for the six frequency samples of one line (10 operations)
+__device__ __forceinline__ void output_transform6(const float (&m)[6], float (&y)[4]) {
+    const float p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+    y[0] = m[0] + p + r;
+    y[1] = fmaf(2.0f, s, q);
+    y[2] = fmaf(4.0f, r, p);
+    y[3] = fmaf(8.0f, s, q) + m[5];
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArgs a) {
+    using T = Wino4Tile;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, k4 = lane >> 4;       // lane roles in an MFMA: tile column / channel of the K = 4 step
+    const int trow = wave & 3, chalf = wave >> 2;    // wave roles: tile row / 16-channel half
+    const int HW = a.H * a.W, G = gridDim.x;
+    const int Ltotal = a.wino_items;
+    const int nchunks = (a.Cin + T::CK - 1) / T::CK;
+
+    auto next_valid = [&](int L) __attribute__((always_inline)) {      // first valid item at or after L in this workgroup's sequence
+        while (L < Ltotal && !decode_item(a, L).valid) L += G;
+        return L;
+    };
+
+    // ------------------------------------------------------------------------------------------------------------
+    // DMA side ("issue cursor"), as in the F(2x2) kernel
+    // ------------------------------------------------------------------------------------------------------------
+    int iL = next_valid(blockIdx.x), ileft = 0, iseq = -1, inb = 0;
+    unsigned in_bytes_left = 0;
+    const char *in_ptr = nullptr, *w_ptr = nullptr;
+    bool iborder = false, ifirst = false;
+    unsigned voff[T::IN_X1], woff[T::W_INSTR];
+    const unsigned in_chunk_bytes = (unsigned)T::CK * (unsigned)HW * 4u, w_chunk_bytes = (unsigned)T::CK * (unsigned)T::NPOS * 4u * (unsigned)a.Cout_pad;
+    auto setup_issue = [&]() __attribute__((always_inline)) {
+        const Item it = decode_item(a, iL);
+        ++iseq;
+        ifirst = true;
+        inb = it.nb;
+        ileft = nchunks;
+        in_ptr = reinterpret_cast<const char *>(a.x + (size_t)it.n * a.x_bs);
+        in_bytes_left = (unsigned)a.Cin * (unsigned)HW * 4u;       // (host: Cin*H*W*4 < 2^32)
+        w_ptr = reinterpret_cast<const char *>(a.wp);
+        iborder = it.x0 == 0 || it.x0 + T::TW >= a.W;      // a fetched 16-byte piece with columns in use would wrap around an image row
+        if (iborder) {
+#pragma unroll
+            for (int i = 0; i < T::IN_X1; ++i) {
+                const int e = 64 * (wave + T::WAVES * i) + lane;     // LDS dword inside the buffer's input part
+                const int c = e / T::PLANE_S, rem = e % T::PLANE_S, r = rem / T::ROWP, xx = rem % T::ROWP;
+                int gy = it.y0 - 1 + r, gx = it.x0 - 1 + xx;
+                bool ok = c < T::CK && rem < T::PLANE && xx < T::TW + 2;
+                if (a.pad_mode == 1) {
+                    gy = reflect_index(gy, a.H);
+                    gx = reflect_index(gx, a.W);
+                } else {
+                    ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                }
+                voff[i] = ok ? (unsigned)(c * HW + gy * a.W + gx) * 4u : 0xffffffffu;   // out of range -> the DMA writes 0
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < T::IN_X4; ++t) {
+                const int f = 64 * (wave + T::WAVES * t) + lane;     // float4 piece inside the buffer's input part
+                const int c = f / T::PIECES, rem = f % T::PIECES, r = rem / T::ROW_PIECES, q = rem % T::ROW_PIECES;
+                int gy = it.y0 - 1 + r;
+                bool ok = c < T::CK && rem < T::PLANE / 4;
+                if (a.pad_mode == 1) gy = reflect_index(gy, a.H);
+                else ok = ok && gy >= 0 && gy < a.H;
+                voff[t] = ok ? (unsigned)(c * HW + gy * a.W + it.x0 - 1 + 4 * q) * 4u : 0xffffffffu;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T::W_INSTR; ++t) {
+            const int f = 64 * (wave + T::WAVES * t) + lane;         // float4 inside the slab [4 cin][9 groups][32 cout][4]
+            woff[t] = (unsigned)(((f / T::BN) * a.Cout_pad + it.nb * T::BN + f % T::BN) * 16);      // (issued only for f < W_FLOATS / 4)
+        }
+    };
+    // The DMA requests of the next chunk of this workgroup's item sequence into ring slot `slot`.  One workgroup per CU
+    // means that all eight waves reach this point together: issued in one go, 38 requests queue up in front of the
+    // texture addresser and every wave sits behind them, so the requests of an interior tile are handed out ONE AT A TIME
+    // (the caller spreads them over the chunk's rows of MFMAs: wave-instruction w + 8 t of the input part for t < 3, of
+    // the weight part for t >= 3); only the per-element requests of an image-border tile go out at once.  Past the end of
+    // the sequence the requests are still issued, empty, so that the counted wait below stays valid.
+    struct Dma {
+        float *buf;
+        bool live, x4;
+    };
+    auto dma_begin = [&](int slot) __attribute__((always_inline)) {
+        float *b = lds + uni(slot) * T::BUF;
+        const bool live = uni(iL) < Ltotal, border = live && uni(iborder ? 1 : 0) != 0;
+        if (border) {
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(uni(in_ptr), (unsigned)uni((int)in_bytes_left));
+#pragma unroll
+            for (int i = 0; i < T::IN_X1; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(b + 64 * (wave + T::WAVES * i)),
+                                                         4, voff[i], 0, 0, 0);
+        }
+        // the item's bias goes through LDS as well (an ordinary load would make the compiler drain the DMA ring)
+        if (live && uni(ifirst ? 1 : 0) != 0 && uni(wave) == 0) {
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? a.bias : a.x, a.bias ? (unsigned)a.Cout * 4u : 0u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(lds + T::BIAS_OFF + (uni(iseq) & (T::BIAS_SLOTS - 1)) * 64),
+                                                     4, lane < T::BN ? (unsigned)(uni(inb) * T::BN + lane) * 4u : 0xffffffffu, 0, 0, 0);
+        }
+        ifirst = false;
+        return Dma{b, live, !border};
+    };
+    auto dma_piece = [&](const Dma &d, int k) __attribute__((always_inline)) {      // k = 0 .. 5 (a constant after unrolling)
+        if (k < T::IN_X4) {
+            if (d.x4 && uni(wave) + T::WAVES * k < T::IN_WI) {
+                const __amdgpu_buffer_rsrc_t rin = make_rsrc(uni(in_ptr), d.live ? (unsigned)uni((int)in_bytes_left) : 0u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(d.buf + 256 * (wave + T::WAVES * k)),
+                                                         16, voff[k], 0, 0, 0);
+            }
+        } else {
+            const int t = k - T::IN_X4;
+            if (uni(wave) + T::WAVES * t < T::W_WI) {
+                const __amdgpu_buffer_rsrc_t rw = make_rsrc(uni(w_ptr), d.live ? w_chunk_bytes : 0u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(d.buf + T::IN_FLOATS + 256 * (wave + T::WAVES * t)),
+                                                         16, woff[t], 0, 0, 0);
+            }
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {       // moves the cursor past the chunk just requested
+        if (uni(iL) < Ltotal) {
+            in_ptr += in_chunk_bytes;
+            w_ptr += w_chunk_bytes;
+            in_bytes_left = in_bytes_left > in_chunk_bytes ? in_bytes_left - in_chunk_bytes : 0u;
+            if (--ileft == 0) {
+                iL = next_valid(iL + G);
+                if (iL < Ltotal) setup_issue();
+            }
+        }
+    };
+    auto issue_next = [&](int slot) __attribute__((always_inline)) {      // (prologue: nothing to interleave with)
+        const Dma d = dma_begin(slot);
+#pragma unroll
+        for (int k = 0; k < T::IN_X4 + T::W_INSTR; ++k) dma_piece(d, k);
+        advance();
+    };
+    if (iL < Ltotal) setup_issue();
+#pragma unroll
+    for (int p = 0; p < T::NBUF - 1; ++p) issue_next(p);
+
+    // ------------------------------------------------------------------------------------------------------------
+    // MFMA side
+    // ------------------------------------------------------------------------------------------------------------
+    const int b_base = k4 * T::PLANE_S + (4 * trow) * T::ROWP + 4 * n16;
+    const int a_base = T::IN_FLOATS + (k4 * T::NGRP * T::BN + chalf * 16 + n16) * 4;
+    f32x4 acc[T::NPOS];     // frequency position 6*i + j
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < T::NPOS; ++p) acc[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+
+    int cL = next_valid(blockIdx.x);
+    if (cL >= Ltotal) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    Item it = decode_item(a, cL);
+    int ch = 0, slot = 0, cseq = 0;
+    zero_acc();
+    // Interior requests per wave and chunk: waves 0,1: 3 + 3, waves 2,3: 3 + 2, waves 4..7: 2 + 2 (border tiles: more).
+    // Chunk c has landed once only the requests of chunks c+1, c+2 are outstanding (an item's stores in between only make
+    // the wait earlier): the count must not exceed what two chunks issue at least.
+    static_assert(T::NBUF == 4 && T::IN_WI == 20 && T::W_WI == 18, "update the counted waits");
+    while (true) {
+        if (wave < 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // the barrier makes every wave's part of chunk c visible and retires everyone's reads of chunk c-1, whose slot the
+        // requests of chunk c+3 then take
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const Dma dma = dma_begin(slot == 0 ? T::NBUF - 1 : slot - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // this lane's raw 6x6 patch; t = B^T d by columns, then V = t B row by row: the MFMAs of a row of positions go
+        // out as soon as that row of V exists, and the next row's 13 operations fill their shadow
+        float t[6][6];
+        {
+            const float *in_s = lds + slot * T::BUF + b_base;
+            float d[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const float4 lo = *reinterpret_cast<const float4 *>(in_s + r * T::ROWP);
+                const float2 hi = *reinterpret_cast<const float2 *>(in_s + r * T::ROWP + 4);
+                d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = lo.z; d[r][3] = lo.w; d[r][4] = hi.x; d[r][5] = hi.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+                float o[6];
+                input_transform6(col, o);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+            }
+        }
+        {
+            const float *w_s = lds + slot * T::BUF + a_base;
+            float4 u[T::NGRP];
+#pragma unroll
+            for (int g = 0; g < T::NGRP; ++g) u[g] = *reinterpret_cast<const float4 *>(w_s + g * T::BN * 4);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float v[6];
+                input_transform6(t[i], v);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int p = 6 * i + j;
+                    const float4 &ug = u[p / 4];
+                    const float ue = (p % 4) == 0 ? ug.x : (p % 4) == 1 ? ug.y : (p % 4) == 2 ? ug.z : ug.w;
+                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(ue, v[j], acc[p], 0, 0, 0);
+                }
+                dma_piece(dma, i);          // one request of chunk c+3 behind every row of MFMAs
+            }
+        }
+        advance();
+        slot = slot + 1 == T::NBUF ? 0 : slot + 1;
+        ++ch;
+        if (ch == nchunks) {
+            // ---- item epilogue: Y = A^T M A per lane: channel co = nb*32 + chalf*16 + 4*k4 + j, tile (row trow, column n16) ----
+            const int gx = it.x0 + 4 * n16, gy0 = it.y0 + 4 * trow;
+            float *__restrict__ yp = a.y + (size_t)it.n * a.y_bs;
+            const int act = ACT;
+            const int co0 = it.nb * T::BN + chalf * 16 + 4 * k4;
+            const float *bias_l = lds + T::BIAS_OFF + (cseq & (T::BIAS_SLOTS - 1)) * 64 + chalf * 16 + 4 * k4;
+            const bool vec4 = (a.W % 4 == 0) && ((reinterpret_cast<size_t>(yp) & 15) == 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float tt[4][6];        // A^T M: 4 x 6
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float col[6] = {acc[c][j], acc[6 + c][j], acc[12 + c][j], acc[18 + c][j], acc[24 + c][j], acc[30 + c][j]};
+                    float o[4];
+                    output_transform6(col, o);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tt[r][c] = o[r];
+                }
+                const float b = bias_l[j];
+                if (co0 + j < a.Cout) {
+                    float *pc = yp + (size_t)(co0 + j) * HW;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float o[4];
+                        output_transform6(tt[r], o);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = apply_act(o[c] + b, act);
+                        const int gy = gy0 + r;
+                        if (gy < a.H) {
+                            if (vec4) {
+                                if (gx < a.W) *reinterpret_cast<float4 *>(pc + (size_t)gy * a.W + gx) = make_float4(o[0], o[1], o[2], o[3]);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (gx + c < a.W) pc[(size_t)gy * a.W + gx + c] = o[c];
+                            }
+                        }
+                    }
+                }
+            }
+            const int nL = next_valid(cL + G);
+            if (nL >= Ltotal) break;
+            cL = nL;
+            ++cseq;
+            it = decode_item(a, cL);
+            ch = 0;
+            zero_acc();
+        }
+    }
+    // the (empty) look-ahead DMAs must have retired before the workgroup's LDS can be handed to another workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// 3x3 OIHW -> F(4x4,3x3) weights U = G g G^T (6x6) as [Cin_pad][9 groups of 4 positions][Cout_pad][4], BatchNorm scale
+// folded.  G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]; in double, rounded once.
+__global__ void conv2d_pack_winograd4_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                             float *__restrict__ out, int Cout, int Cin, int Cin_pad, int Cout_pad) {
+    const size_t total = (size_t)Cin_pad * 36 * Cout_pad;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j4 = e & 3, co = (e >> 2) % Cout_pad, g = (e / ((size_t)4 * Cout_pad)) % 9, ci = e / ((size_t)36 * Cout_pad);
+        const int p = 4 * g + j4, i = p / 6, j = p % 6;
+        double u = 0.0;
+        if (co < Cout && ci < Cin) {
+            const float *k = w + ((size_t)co * Cin + ci) * 9;
+            const double Gm[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) u += Gm[i][r] * (double)k[r * 3 + c] * Gm[j][c];
+            if (scale) u *= (double)scale[co];
+        }
+        out[e] = (float)u;
+    }
+}
+
+}  // namespace
+
+void vfi::conv::launch_pack_winograd4(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin, int Cin_pad,
+                                      int Cout_pad, hipStream_t s) {
+    const long long total = (long long)Cin_pad * 36 * Cout_pad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv2d_pack_winograd4_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, scale, packed, Cout, Cin, Cin_pad, Cout_pad);
+}
+
+// Whether a layer goes to the F(4x4) kernel: plain (the caller checks residual / pooled output), one K split's worth of
+// items for every resident workgroup several times over, 32-bit offsets.
+bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
+    using T = Wino4Tile;
+    static const int mode = getenv("VFI_CONV_WINOGRAD4") ? atoi(getenv("VFI_CONV_WINOGRAD4")) : 0;      // 2: every plain layer (tests)
+    if (!mode || a.res || a.pool) return false;
+    const long long items = (long long)vfi::ceil_div(a.W, T::TW) * vfi::ceil_div(a.H, T::TH) * N * (a.Cout_pad / T::BN);
+    return (mode == 2 || items >= 4 * 256) && items < (1ll << 28);
+}
+
+int vfi::conv::launch_winograd4(const ConvArgs &a, int N, hipStream_t s) {
+    using T = Wino4Tile;
+    static int resident_dev[vfi::kMaxDevices] = {};   // persistent grid: 1 workgroup per CU; per device, idempotent
+    int &resident = resident_dev[vfi::current_device()];
+    if (!resident) {
+        hipError_t e = hipSuccess;
+        for (const void *k : {reinterpret_cast<const void *>(conv3x3_winograd4_kernel<0>), reinterpret_cast<const void *>(conv3x3_winograd4_kernel<1>),
+                              reinterpret_cast<const void *>(conv3x3_winograd4_kernel<2>), reinterpret_cast<const void *>(conv3x3_winograd4_kernel<3>),
+                              reinterpret_cast<const void *>(conv3x3_winograd4_kernel<4>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+        int dev = 0, cus = 0;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || cus <= 0) return vfi::fail(VFI_ERR_LAUNCH, "vfi_conv2d: Winograd F(4x4) kernel setup: %s", hipGetErrorString(e));
+        resident = cus;
+    }
+    ConvArgs b = a;
+    const int cb = a.Cout_pad / T::BN;
+    b.tiles_x = vfi::ceil_div(a.W, T::TW);
+    b.wino_tiles = b.tiles_x * vfi::ceil_div(a.H, T::TH);
+    b.wino_batch = N;
+    b.wino_run = 1;
+    while (b.wino_run < 8 && (long long)b.wino_tiles * N >= 256ll * 2 * b.wino_run) b.wino_run *= 2;
+    b.wino_items = round_up(b.wino_tiles * N, 8 * b.wino_run) * cb;
+    b.splits = 1;
+    b.fd_items = make_fastdiv((unsigned)b.wino_items);
+    b.fd_cb = make_fastdiv((unsigned)cb);
+    b.fd_run = make_fastdiv((unsigned)b.wino_run);
+    b.fd_tiles = make_fastdiv((unsigned)b.wino_tiles);
+    b.fd_tiles_x = make_fastdiv((unsigned)b.tiles_x);
+    b.fd_splits = make_fastdiv(1u);
+    dim3 grid((unsigned)(b.wino_items < resident ? b.wino_items : resident));
+    if (b.act == 0) hipLaunchKernelGGL((conv3x3_winograd4_kernel<0>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
+    else if (b.act == 1) hipLaunchKernelGGL((conv3x3_winograd4_kernel<1>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
+    else if (b.act == 2) hipLaunchKernelGGL((conv3x3_winograd4_kernel<2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
+    else if (b.act == 3) hipLaunchKernelGGL((conv3x3_winograd4_kernel<3>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
+    else hipLaunchKernelGGL((conv3x3_winograd4_kernel<4>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
+    return vfi::check_launch("vfi_conv2d");
+}
