@@ -412,7 +412,9 @@ void vfi::conv::launch_pack_winograd4(const float *w_oihw, const float *scale, f
 // items for every resident workgroup several times over, 32-bit offsets.
 bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
     using T = Wino4Tile;
-    static const int mode = getenv("VFI_CONV_WINOGRAD4") ? atoi(getenv("VFI_CONV_WINOGRAD4")) : 0;      // 2: every plain layer (tests)
+    // VFI_CONV_WINOGRAD4: 0 = never (A/B aid: the F(2x2) kernel takes everything), 2 = every plain layer whatever its size
+    // (fuzzing small shapes through this kernel); default 1
+    static const int mode = getenv("VFI_CONV_WINOGRAD4") ? atoi(getenv("VFI_CONV_WINOGRAD4")) : 1;
     if (!mode || a.res || a.pool) return false;
     const long long items = (long long)vfi::ceil_div(a.W, T::TW) * vfi::ceil_div(a.H, T::TH) * N * (a.Cout_pad / T::BN);
     return (mode == 2 || items >= 4 * 256) && items < (1ll << 28);

@@ -57,6 +57,30 @@ def test_conv_matches_torch_cpu(n, cin, cout, h, w, ks, pad, act, device):
     assert err <= 2e-5, err
 
 
+BIG_CASES = [
+    # plain 3x3 layers with enough work items for the F(4x4,3x3) Winograd kernel (csrc/vfi_conv_winograd4.hip): 16x64 tiles
+    # n, cin, cout, h, w, pad, act
+    (1, 8, 32, 512, 2048, "zeros", "relu"),       # exact tiles
+    (2, 10, 40, 250, 2044, "reflect", None),      # ragged tile rows / columns, Cin and Cout tails, two channel blocks
+    (1, 6, 64, 500, 1026, "zeros", "elu"),        # row length not a multiple of 4: element-wise stores
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,pad,act", BIG_CASES)
+def test_large_plain_conv_matches_torch_cpu(n, cin, cout, h, w, pad, act, device):
+    g = torch.Generator().manual_seed(cin * 1000 + cout + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wgt = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    ref = _ref(x.double(), wgt.double(), b.double(), 3, pad, act)
+    pc = ops.PackedConv(wgt, b, device=device)
+    out = ops.conv2d(x.to(device), pc, pad, act)
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs()
+    # the larger Winograd tile costs about a decimal digit: rms 2e-6, maximum 3e-5 of the output rms
+    assert err.max().item() <= 1e-4 and err.pow(2).mean().sqrt().item() <= 5e-6, (err.max().item(), err.pow(2).mean().sqrt().item())
+
+
 def test_conv_bn_fold_residual_and_channel_slices(device):
     g = torch.Generator().manual_seed(0)
     n, h, w = 2, 20, 36
