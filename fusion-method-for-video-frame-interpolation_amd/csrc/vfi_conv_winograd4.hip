@@ -1,7 +1,7 @@
 // 3x3 convolutions (stride 1, "same" size, zero or reflect padding) with the larger Winograd tile F(4x4, 3x3) on the
 // gfx950 matrix cores (v_mfma_f32_16x16x4_f32): 36 multiply-adds per 4x4 outputs and channel pair instead of the 64 of
-// F(2x2, 3x3) (vfi_conv_winograd.hip), i.e. 1.78x fewer MFMAs, for plain layers (bias + activation, no residual, no
-// pooled output, no K split) that are large enough to fill the chip; everything else stays with the F(2x2) kernel.
+// F(2x2, 3x3) (vfi_conv_winograd.hip), i.e. 1.78x fewer MFMAs, for layers without a K split that are large enough to fill
+// the chip; everything else stays with the F(2x2) kernel.
 //
 //   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A     with the 6x6 transforms of the points {0, +-1, +-2, inf}
 //
@@ -114,7 +114,10 @@ __device__ __forceinline__ void output_transform6(const float (&m)[6], float (&y
     y[3] = fmaf(8.0f, s, q) + m[5];
 }
 
-template <int ACT>
+// ACT: the activation as a compile-time constant (-1: read it from the arguments).  RES: a residual tensor is added after
+// the activation.  POOL: the lane that holds a 4x4 output block also writes its four 2x2-pooled values (AvgPool2d /
+// MaxPool2d(2) after the layer: no separate pass re-reads the output; same evaluation order as vfi_pool2).
+template <int ACT, bool RES = false, bool POOL = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArgs a) {
     using T = Wino4Tile;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -328,10 +331,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
             // ---- item epilogue: Y = A^T M A per lane: channel co = nb*32 + chalf*16 + 4*k4 + j, tile (row trow, column n16) ----
             const int gx = it.x0 + 4 * n16, gy0 = it.y0 + 4 * trow;
             float *__restrict__ yp = a.y + (size_t)it.n * a.y_bs;
-            const int act = ACT;
+            const int act = ACT >= 0 ? ACT : a.act;
             const int co0 = it.nb * T::BN + chalf * 16 + 4 * k4;
             const float *bias_l = lds + T::BIAS_OFF + (cseq & (T::BIAS_SLOTS - 1)) * 64 + chalf * 16 + 4 * k4;
-            const bool vec4 = (a.W % 4 == 0) && ((reinterpret_cast<size_t>(yp) & 15) == 0);
+            const float *__restrict__ resp = RES ? a.res + (size_t)it.n * a.res_bs : nullptr;
+            const bool vec4 = (a.W % 4 == 0) && ((reinterpret_cast<size_t>(yp) & 15) == 0) && (!RES || (reinterpret_cast<size_t>(resp) & 15) == 0);
+            const int Hq = a.H >> 1, Wq = a.W >> 1;       // pooled plane; this lane's block -> rows gy0/2 .., columns gx/2 ..
+            float *__restrict__ pq = POOL ? a.pool + (size_t)it.n * a.pool_bs + (size_t)(gy0 >> 1) * Wq + (gx >> 1) : nullptr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float tt[4][6];        // A^T M: 4 x 6
@@ -345,7 +351,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
                 }
                 const float b = bias_l[j];
                 if (co0 + j < a.Cout) {
-                    float *pc = yp + (size_t)(co0 + j) * HW;
+                    const size_t plane = (size_t)(co0 + j) * HW;
+                    float *pc = yp + plane;
+                    float prev[4];         // (POOL) the activated row above
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float o[4];
@@ -353,13 +361,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[c] = apply_act(o[c] + b, act);
                         const int gy = gy0 + r;
+                        if (POOL) {
+                            if (r & 1) {
+                                const int qy = (gy0 >> 1) + (r >> 1);
+#pragma unroll
+                                for (int cc = 0; cc < 2; ++cc) {
+                                    const float p0 = prev[2 * cc], p1 = prev[2 * cc + 1], p2 = o[2 * cc], p3 = o[2 * cc + 1];
+                                    const float pv = a.pool_max ? fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)) : (p0 + p1 + p2 + p3) * 0.25f;
+                                    if (qy < Hq && (gx >> 1) + cc < Wq) pq[(size_t)(co0 + j) * Hq * Wq + (size_t)(r >> 1) * Wq + cc] = pv;
+                                }
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) prev[c] = o[c];
+                            }
+                        }
                         if (gy < a.H) {
                             if (vec4) {
-                                if (gx < a.W) *reinterpret_cast<float4 *>(pc + (size_t)gy * a.W + gx) = make_float4(o[0], o[1], o[2], o[3]);
+                                if (gx < a.W) {
+                                    float4 q = make_float4(o[0], o[1], o[2], o[3]);
+                                    if (RES) {
+                                        const float4 rr = *reinterpret_cast<const float4 *>(resp + plane + (size_t)gy * a.W + gx);
+                                        q.x += rr.x; q.y += rr.y; q.z += rr.z; q.w += rr.w;
+                                    }
+                                    *reinterpret_cast<float4 *>(pc + (size_t)gy * a.W + gx) = q;
+                                }
                             } else {
 #pragma unroll
                                 for (int c = 0; c < 4; ++c)
-                                    if (gx + c < a.W) pc[(size_t)gy * a.W + gx + c] = o[c];
+                                    if (gx + c < a.W) pc[(size_t)gy * a.W + gx + c] = o[c] + (RES ? resp[plane + (size_t)gy * a.W + gx + c] : 0.0f);
                             }
                         }
                     }
@@ -415,7 +444,8 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
     // VFI_CONV_WINOGRAD4: 0 = never (A/B aid: the F(2x2) kernel takes everything), 2 = every plain layer whatever its size
     // (fuzzing small shapes through this kernel); default 1
     static const int mode = getenv("VFI_CONV_WINOGRAD4") ? atoi(getenv("VFI_CONV_WINOGRAD4")) : 1;
-    if (!mode || a.res || a.pool) return false;
+    if (!mode) return false;
+    if (a.pool && (a.res || a.act != 1)) return false;          // pooled output: plain ReLU layers only (as the F(2x2) kernel fuses it)
     const long long items = (long long)vfi::ceil_div(a.W, T::TW) * vfi::ceil_div(a.H, T::TH) * N * (a.Cout_pad / T::BN);
     return (mode == 2 || items >= 4 * 256) && items < (1ll << 28);
 }
@@ -428,7 +458,8 @@ int vfi::conv::launch_winograd4(const ConvArgs &a, int N, hipStream_t s) {
         hipError_t e = hipSuccess;
         for (const void *k : {reinterpret_cast<const void *>(conv3x3_winograd4_kernel<0>), reinterpret_cast<const void *>(conv3x3_winograd4_kernel<1>),
                               reinterpret_cast<const void *>(conv3x3_winograd4_kernel<2>), reinterpret_cast<const void *>(conv3x3_winograd4_kernel<3>),
-                              reinterpret_cast<const void *>(conv3x3_winograd4_kernel<4>)})
+                              reinterpret_cast<const void *>(conv3x3_winograd4_kernel<4>), reinterpret_cast<const void *>(conv3x3_winograd4_kernel<-1, true>),
+                              reinterpret_cast<const void *>(conv3x3_winograd4_kernel<1, false, true>)})
             if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
         int dev = 0, cus = 0;
         if (e == hipSuccess) e = hipGetDevice(&dev);
@@ -452,7 +483,9 @@ int vfi::conv::launch_winograd4(const ConvArgs &a, int N, hipStream_t s) {
     b.fd_tiles_x = make_fastdiv((unsigned)b.tiles_x);
     b.fd_splits = make_fastdiv(1u);
     dim3 grid((unsigned)(b.wino_items < resident ? b.wino_items : resident));
-    if (b.act == 0) hipLaunchKernelGGL((conv3x3_winograd4_kernel<0>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
+    if (b.pool) hipLaunchKernelGGL((conv3x3_winograd4_kernel<1, false, true>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
+    else if (b.res) hipLaunchKernelGGL((conv3x3_winograd4_kernel<-1, true>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
+    else if (b.act == 0) hipLaunchKernelGGL((conv3x3_winograd4_kernel<0>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
     else if (b.act == 1) hipLaunchKernelGGL((conv3x3_winograd4_kernel<1>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
     else if (b.act == 2) hipLaunchKernelGGL((conv3x3_winograd4_kernel<2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);
     else if (b.act == 3) hipLaunchKernelGGL((conv3x3_winograd4_kernel<3>), grid, dim3(T::THREADS), T::LDS_BYTES, s, b);

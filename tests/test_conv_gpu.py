@@ -81,6 +81,22 @@ def test_large_plain_conv_matches_torch_cpu(n, cin, cout, h, w, pad, act, device
     assert err.max().item() <= 1e-4 and err.pow(2).mean().sqrt().item() <= 5e-6, (err.max().item(), err.pow(2).mean().sqrt().item())
 
 
+def test_large_conv_with_residual_matches_torch_cpu(device):
+    # the residual variant of the F(4x4) Winograd kernel (PhaseNet blocks at full resolution): act(conv + b) + residual
+    n, cin, cout, h, w = 2, 12, 64, 270, 1920
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((n, cin, h, w), generator=g)
+    res = torch.randn((n, cout, h, w), generator=g)
+    wgt = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    ref = _ref(x.double(), wgt.double(), b.double(), 3, "reflect", "elu", res=res.double())
+    pc = ops.PackedConv(wgt, b, device=device)
+    out = ops.conv2d(x.to(device), pc, "reflect", "elu", residual=res.to(device))
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs()
+    assert err.max().item() <= 1e-4 and err.pow(2).mean().sqrt().item() <= 5e-6, (err.max().item(), err.pow(2).mean().sqrt().item())
+
+
 def test_conv_bn_fold_residual_and_channel_slices(device):
     g = torch.Generator().manual_seed(0)
     n, h, w = 2, 20, 36
@@ -245,7 +261,9 @@ def test_winograd_conv_one_chunk_items_keep_their_bias(device):
 
 @pytest.mark.parametrize("n,cin,cout,h,w,ks,is_max,pad", [(2, 6, 32, 64, 96, 3, False, "zeros"), (1, 64, 128, 40, 72, 3, True, "reflect"),
                                                          (1, 32, 64, 37, 51, 3, False, "zeros"), (1, 512, 512, 8, 12, 3, False, "zeros"),
-                                                         (1, 18, 32, 40, 72, 5, True, "reflect")])
+                                                         (1, 18, 32, 40, 72, 5, True, "reflect"),
+                                                         # large enough for the F(4x4) Winograd kernel, ragged / odd sizes
+                                                         (1, 8, 32, 512, 2048, 3, False, "zeros"), (2, 6, 40, 251, 2046, 3, True, "reflect")])
 def test_conv_with_fused_pooling_equals_conv_then_pool(n, cin, cout, h, w, ks, is_max, pad, device):
     # vfi_conv2d_pool2: the pooled tensor written by the Winograd epilogue (3x3 ReLU layers in one piece), or by a pooling
     # pass behind split-K / direct layers -- bit-identical to conv2d followed by pool2 either way; odd sizes floor
