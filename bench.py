@@ -289,9 +289,13 @@ def main():
                                 "algorithmic_gflop_per_launch": d["work"] / d["calls"] / 1e9}
             if traffic_note:
                 line["roofline"]["traffic_note"] = traffic_note
-            if "winograd" in dom:
-                # `achieved` counts the Winograd algorithm's own multiply-adds (16 per 2x2 outputs and channel pair: what
-                # the matrix cores execute); the same convolutions done directly are 36
+            if "winograd4" in dom:
+                # `achieved` counts the Winograd algorithm's own multiply-adds (36 per 4x4 outputs and channel pair: what
+                # the matrix cores execute); the same convolutions done directly are 144
+                line["roofline"]["flops_counted"] = "Winograd F(4x4,3x3): 2*N*Cin*Cout*36*(H*W/16) per launch"
+                line["roofline"]["direct_conv_equivalent_tflops"] = tf * 4.0
+            elif "winograd" in dom:
+                # (16 per 2x2 outputs and channel pair; directly: 36)
                 line["roofline"]["flops_counted"] = "Winograd F(2x2,3x3): 2*N*Cin*Cout*16*(H*W/4) per launch"
                 line["roofline"]["direct_conv_equivalent_tflops"] = tf * 2.25
             line["roofline_other"] = []

@@ -447,7 +447,9 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
     if (!mode) return false;
     if (a.pool && (a.res || a.act != 1)) return false;          // pooled output: plain ReLU layers only (as the F(2x2) kernel fuses it)
     const long long items = (long long)vfi::ceil_div(a.W, T::TW) * vfi::ceil_div(a.H, T::TH) * N * (a.Cout_pad / T::BN);
-    return (mode == 2 || items >= 3 * 256) && items < (1ll << 28);      // (measured: pays from ~4 items per workgroup; 544 items: 1.4x slower)
+    // (measured per layer of the 1080p frame: wins from 2040 items up, loses at 1632 and below -- few long items against
+    // the F(2x2) kernel's twice as many resident workgroups and its K split)
+    return (mode == 2 || items >= 2000) && items < (1ll << 28);
 }
 
 int vfi::conv::launch_winograd4(const ConvArgs &a, int N, hipStream_t s) {

@@ -74,6 +74,19 @@ WINOGRAD = os.environ.get("VFI_CONV_WINOGRAD", "1") != "0"     # mirrors the lib
 FUSED_RESIZE = (not WINOGRAD) or os.environ.get("VFI_CONV_FUSED_RESIZE", "0") == "1"
 # (measured again in round 2 for the thin 25 -> 25 head convolutions alone: the fused loader loses there too,
 # 77.5 vs 72.2 ms per frame)
+WINOGRAD4 = int(os.environ.get("VFI_CONV_WINOGRAD4", "1"))     # mirrors csrc/vfi_conv_winograd4.hip: winograd4_suits (labels only)
+
+
+def _winograd_work(n, cin, cout, h, w, residual=False, pooled=False, act="relu"):
+    """Profiling label and the executed algorithm's own flop count of a 3x3 layer: F(4x4,3x3) -- 36 multiply-adds per 4x4
+    outputs and channel pair -- where the library picks that kernel (large layers), else F(2x2,3x3) -- 16 per 2x2."""
+    items = -(-w // 64) * -(-h // 16) * n * (-(-cout // 32))
+    big = WINOGRAD4 and (WINOGRAD4 == 2 or items >= 2000) and not (pooled and (residual or act != "relu"))
+    if big:
+        return ("flop", 2.0 * n * cin * cout * 36 * (h * w / 16.0), "conv3x3_winograd4_kernel")
+    return ("flop", 2.0 * n * cin * cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")
+
+
 _WORKSPACES = {}
 WORKSPACE_FLOATS = 48 * 1024 * 1024     # 192 MiB per (device, stream): split-K partial sums of the deep U-Net levels
 
@@ -116,8 +129,7 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2
     work = None
     if _lib.PROFILE is not None:
         if pc.ks == 3 and not upsample2x and WINOGRAD:
-            # F(2x2,3x3): 16 multiply-adds per 2x2 outputs and channel pair -- the algorithm's own flop count
-            work = ("flop", 2.0 * n * cin * pc.cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")
+            work = _winograd_work(n, cin, pc.cout, h, w, residual is not None, False, act)
         else:
             label = (f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}"
                      + (",ups>" if upsample2x else ">"))
@@ -143,7 +155,7 @@ def conv2d_pool2(x, pc, is_max, pad_mode="zeros", act="relu"):
     work = None
     if _lib.PROFILE is not None:
         if pc.ks == 3 and WINOGRAD:
-            work = ("flop", 2.0 * n * cin * pc.cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")
+            work = _winograd_work(n, cin, pc.cout, h, w, False, True, act)
         else:
             work = ("flop", 2.0 * n * cin * pc.cout * pc.ks * pc.ks * h * w,
                     f"conv2d_mfma_kernel<{pc.ks},{4 if pc.ks == 5 else 8},{2 if ((pc.cout + 31) // 32 * 32) % 64 == 0 else 1}>")

@@ -20,7 +20,7 @@ from collections import defaultdict
 csv.field_size_limit(sys.maxsize)
 
 # kernels whose global reads are 16-B-per-lane streams (FETCH_SIZE x 2); label -> substring of the kernel name
-WIDE_READERS = {"conv3x3_winograd_kernel": "conv3x3_winograd_kernel"}
+WIDE_READERS = {"conv3x3_winograd4_kernel": "conv3x3_winograd4_kernel", "conv3x3_winograd_kernel": "conv3x3_winograd_kernel"}
 
 
 def collect(directory, counter):
