@@ -270,40 +270,45 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
     Item it = decode_item(a, cL);
     int ch = 0, slot = 0, cseq = 0;
     zero_acc();
-    // Interior requests per wave and chunk: waves 0,1: 3 + 3, waves 2,3: 3 + 2, waves 4..7: 2 + 2 (border tiles: more).
-    // Chunk c has landed once only the requests of chunks c+1, c+2 are outstanding (an item's stores in between only make
-    // the wait earlier): the count must not exceed what two chunks issue at least.
+    // Interior requests per wave and chunk: waves 0,1: 3 + 3, waves 2,3: 3 + 2, waves 4..7: 2 + 2 (border tiles: more; an
+    // item's stores in between only make a counted wait earlier).
     static_assert(T::NBUF == 4 && T::IN_WI == 20 && T::W_WI == 18, "update the counted waits");
+    auto read_patch = [&](float (&d)[6][6], int sl) __attribute__((always_inline)) {       // this lane's raw 6x6 patch
+        const float *in_s = lds + sl * T::BUF + b_base;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const float4 lo = *reinterpret_cast<const float4 *>(in_s + r * T::ROWP);
+            const float2 hi = *reinterpret_cast<const float2 *>(in_s + r * T::ROWP + 4);
+            d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = lo.z; d[r][3] = lo.w; d[r][4] = hi.x; d[r][5] = hi.y;
+        }
+    };
+    float t[6][6];          // the current chunk's patch, fetched at the end of the chunk before; B^T d in place
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // chunk 0 landed (chunks 1, 2 may be in flight)
+    else if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_patch(t, 0);
     while (true) {
-        if (wave < 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        // the barrier makes every wave's part of chunk c visible and retires everyone's reads of chunk c-1, whose slot the
-        // requests of chunk c+3 then take
+        // Chunk c+1 (whose patch is fetched at the end of this chunk) has landed once only the requests of chunk c+2 are
+        // outstanding; the barrier makes every wave's part visible and retires everyone's reads of chunk c-1, whose slot the
+        // requests of chunk c+3 then take.
+        if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const Dma dma = dma_begin(slot == 0 ? T::NBUF - 1 : slot - 1);
         __builtin_amdgcn_sched_barrier(0);
-        // this lane's raw 6x6 patch; t = B^T d by columns, then V = t B row by row: the MFMAs of a row of positions go
-        // out as soon as that row of V exists, and the next row's 13 operations fill their shadow
-        float t[6][6];
-        {
-            const float *in_s = lds + slot * T::BUF + b_base;
-            float d[6][6];
+        // t = B^T d by columns, then V = t B row by row: the MFMAs of a row of positions go out as soon as that row of V
+        // exists, and the next row's 13 operations fill their shadow
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const float4 lo = *reinterpret_cast<const float4 *>(in_s + r * T::ROWP);
-                const float2 hi = *reinterpret_cast<const float2 *>(in_s + r * T::ROWP + 4);
-                d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = lo.z; d[r][3] = lo.w; d[r][4] = hi.x; d[r][5] = hi.y;
-            }
+        for (int j = 0; j < 6; ++j) {
+            const float col[6] = {t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], t[5][j]};
+            float o[6];
+            input_transform6(col, o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
-                float o[6];
-                input_transform6(col, o);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) t[i][j] = o[i];
-            }
+            for (int i = 0; i < 6; ++i) t[i][j] = o[i];
         }
         {
             const float *w_s = lds + slot * T::BUF + a_base;
@@ -324,8 +329,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
                 dma_piece(dma, i);          // one request of chunk c+3 behind every row of MFMAs
             }
         }
-        advance();
         slot = slot + 1 == T::NBUF ? 0 : slot + 1;
+        read_patch(t, slot);                // (behind the last row's MFMAs; after the workgroup's last chunk: an empty slot, unused)
+        advance();
         ++ch;
         if (ch == nchunks) {
             // ---- item epilogue: Y = A^T M A per lane: channel co = nb*32 + chalf*16 + 4*k4 + j, tile (row trow, column n16) ----

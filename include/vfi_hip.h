@@ -17,7 +17,7 @@
  *     Workspace is caller-provided or owned by an explicit plan object.
  *   - Process-wide state is limited to idempotent per-device launch setup (the dynamic-LDS
  *     attribute of three kernels, the CU count), tuning switches read once from the
- *     environment (VFI_CONV_WINOGRAD, VFI_ADACOF_VARIANT, VFI_ADACOF_MARGIN) and the
+ *     environment (VFI_CONV_WINOGRAD, VFI_CONV_WINOGRAD4, VFI_ADACOF_VARIANT, VFI_ADACOF_MARGIN) and the
  *     thread-local last-error string; everything else lives in explicit plan objects,
  *     whose tables are immutable after creation and whose workspace belongs to ONE stream
  *     at a time (frames in flight on different streams use different plans).
@@ -126,8 +126,10 @@ int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int 
  * Replaces every nn.Conv2d (+ following BatchNorm / ReLU / ELU / Tanh / Sigmoid, + the additive U-Net
  * skip) on the path: reference src/phase_net/phase_net.py:190-200, src/fusion_net/fusion_adacofnet.py:18-155,
  * src/fusion_net/fusion_net.py:24-41,56-69.
- * KS = 3 runs Winograd F(2x2,3x3) on the fp32 matrix cores (same result up to fp32 rounding of the transforms:
- * <= 3e-5 on O(1) data; VFI_CONV_WINOGRAD=0 in the environment selects the direct kernel), KS = 1 / 5 the direct one.
+ * KS = 3 runs Winograd on the fp32 matrix cores -- F(2x2,3x3), and F(4x4,3x3) for layers of 2000 or more 16x64 output
+ * tiles x 32-channel blocks (same result up to fp32 rounding of the transforms: rms 3e-7 resp. 2e-6 of the output rms,
+ * <= 3e-5 resp. 1e-4 at worst on O(1) data; VFI_CONV_WINOGRAD4=0 in the environment keeps F(2x2) everywhere,
+ * VFI_CONV_WINOGRAD=0 selects the direct kernel), KS = 1 / 5 the direct one.
  *   x        (N, Cin, H, W); consecutive samples are x_bstride floats apart, so x may be a channel
  *            slice of a wider tensor (no concat / split copies)
  *   residual NULL or (N, Cout, H, W) with stride res_bstride, added AFTER the activation
