@@ -110,7 +110,7 @@ template <bool RES, int ACT, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const ConvArgs a) {
     using T = WinoTile;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(threadIdx.x >> 6));      // (in an SGPR: LDS-DMA destinations are scalar arithmetic)
     const int n16 = lane & 15, k4 = lane >> 4;       // lane roles in an MFMA: tile column / channel of the K = 4 step
     const int HW = a.H * a.W, G = gridDim.x, N = a.wino_batch;
     const int Ltotal = a.wino_items * a.splits;

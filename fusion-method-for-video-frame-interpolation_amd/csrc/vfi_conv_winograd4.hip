@@ -9,7 +9,7 @@
 //     channels: wave w owns tile row w & 3 and the 16-channel half w >> 2 (M = 16 channels, N = 16 tiles, K = 4 input
 //     channels per MFMA; the 36 frequency positions are 36 independent accumulators, 144 registers);
 //   * per K step a lane reads ONE raw 6x6 input patch (its tile, its channel: a 16-byte and an 8-byte LDS read per row),
-//     forms V = B^T d B in registers (12 one-dimensional transforms of 13 operations) and feeds V's 36 entries to 36
+//     forms V = B^T d B in registers (12 one-dimensional transforms of 12 operations) and feeds V's 36 entries to 36
 //     MFMAs whose A operands are the pre-transformed weights U = G g G^T ([cin][group of 4 positions][cout][4] in LDS:
 //     one ds_read_b128 = four positions);
 //   * the 36 position accumulators of one (channel, tile) sit in one lane: the output transform is register-only and
@@ -94,15 +94,15 @@ __device__ __forceinline__ Item decode_item(const ConvArgs &a, int L) {
     return it;
 }
 
-// B^T x for the six samples of one line (13 operations)
+// B^T x for the six samples of one line (12 operations)
 __device__ __forceinline__ void input_transform6(const float (&x)[6], float (&t)[6]) {
     t[0] = fmaf(4.0f, x[0], fmaf(-5.0f, x[2], x[4]));
     const float p = fmaf(-4.0f, x[2], x[4]), q = fmaf(-4.0f, x[1], x[3]);
     t[1] = p + q;
     t[2] = p - q;
-    const float r = x[4] - x[2], s = 2.0f * (x[3] - x[1]);
-    t[3] = r + s;
-    t[4] = r - s;
+    const float r = x[4] - x[2], s = x[3] - x[1];
+    t[3] = fmaf(2.0f, s, r);
+    t[4] = fmaf(-2.0f, s, r);
     t[5] = fmaf(4.0f, x[1], fmaf(-5.0f, x[3], x[5]));
 }
 // A^T m for the six frequency samples of one line (10 operations)
@@ -121,7 +121,8 @@ template <int ACT, bool RES = false, bool POOL = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArgs a) {
     using T = Wino4Tile;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(threadIdx.x >> 6));      // (the wave index lives in an SGPR:
+                                                                                             //  LDS-DMA destinations are scalar arithmetic)
     const int n16 = lane & 15, k4 = lane >> 4;       // lane roles in an MFMA: tile column / channel of the K = 4 step
     const int trow = wave & 3, chalf = wave >> 2;    // wave roles: tile row / 16-channel half
     const int HW = a.H * a.W, G = gridDim.x;
