@@ -209,8 +209,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
         // the item's bias goes through LDS as well (an ordinary load would make the compiler drain the DMA ring)
         if (live && uni(ifirst ? 1 : 0) != 0 && uni(wave) == 0) {
             const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? a.bias : a.x, a.bias ? (unsigned)a.Cout * 4u : 0u);
+            // (the lane index is recomputed here: kept in a register it gets spilled, and its reload -- an ordinary vector
+            // memory load -- has to wait for the whole DMA ring, vmcnt(0))
+            const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(lds + T::BIAS_OFF + (uni(iseq) & (T::BIAS_SLOTS - 1)) * 64),
-                                                     4, lane < T::BN ? (unsigned)(uni(inb) * T::BN + lane) * 4u : 0xffffffffu, 0, 0, 0);
+                                                     4, ln < (unsigned)T::BN ? ((unsigned)uni(inb) * T::BN + ln) * 4u : 0xffffffffu, 0, 0, 0);
         }
         ifirst = false;
         return Dma{b, live, !border};
@@ -278,9 +281,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
         const float *in_s = lds + sl * T::BUF + b_base;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            const float4 lo = *reinterpret_cast<const float4 *>(in_s + r * T::ROWP);
-            const float2 hi = *reinterpret_cast<const float2 *>(in_s + r * T::ROWP + 4);
-            d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = lo.z; d[r][3] = lo.w; d[r][4] = hi.x; d[r][5] = hi.y;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d[r][j] = in_s[r * T::ROWP + j];      // (element-wise: merged to 16- and 8-byte reads, see below)
         }
     };
     float t[6][6];          // the current chunk's patch, fetched at the end of the chunk before; B^T d in place
@@ -315,7 +317,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
             const float *w_s = lds + slot * T::BUF + a_base;
             float4 u[T::NGRP];
 #pragma unroll
-            for (int g = 0; g < T::NGRP; ++g) u[g] = *reinterpret_cast<const float4 *>(w_s + g * T::BN * 4);
+            for (int g = 0; g < T::NGRP; ++g) {
+                // (element-wise: merged to ds_read_b128; NOT through a float4 pointer -- an LDS read the compiler can name waits for
+                //  every outstanding LDS-DMA request, vmcnt(0), because it cannot tell that they do not overlap)
+                const float *pu = w_s + g * T::BN * 4;
+                u[g] = make_float4(pu[0], pu[1], pu[2], pu[3]);
+            }
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 float v[6];
