@@ -461,9 +461,15 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
     if (!mode) return false;
     if (a.pool && (a.res || a.act != 1)) return false;          // pooled output: plain ReLU layers only (as the F(2x2) kernel fuses it)
     const long long items = (long long)vfi::ceil_div(a.W, T::TW) * vfi::ceil_div(a.H, T::TH) * N * (a.Cout_pad / T::BN);
-    // (measured per layer of the 1080p frame: wins from 2040 items up, loses at 1632 and below -- few long items against
-    // the F(2x2) kernel's twice as many resident workgroups and its K split)
-    return (mode == 2 || items >= 2000) && items < (1ll << 28);
+    if (items >= (1ll << 28)) return false;
+    if (mode == 2) return true;
+    // Measured per layer of the 1080p frame against the F(2x2) kernel (twice as many, shorter items; K split): 8-20 %
+    // faster from 2000 items up and where the items fill whole rounds of the 256 resident workgroups (1020, 1530: 4 and 6
+    // rounds; 216..510: one or two), slower where the last round is mostly empty (272, 544, 816) and for 6 -> 32 layers.
+    if (a.Cin < 16) return false;
+    const long long rounds = (items + 255) / 256;
+    const bool full_rounds = items * 100 >= rounds * 256 * 84;
+    return items >= 2000 || (items >= 1000 && items < 1600) || (items <= 512 && items >= 200 && full_rounds);
 }
 
 int vfi::conv::launch_winograd4(const ConvArgs &a, int N, hipStream_t s) {

@@ -81,7 +81,10 @@ def _winograd_work(n, cin, cout, h, w, residual=False, pooled=False, act="relu")
     """Profiling label and the executed algorithm's own flop count of a 3x3 layer: F(4x4,3x3) -- 36 multiply-adds per 4x4
     outputs and channel pair -- where the library picks that kernel (large layers), else F(2x2,3x3) -- 16 per 2x2."""
     items = -(-w // 64) * -(-h // 16) * n * (-(-cout // 32))
-    big = WINOGRAD4 and (WINOGRAD4 == 2 or items >= 2000) and not (pooled and (residual or act != "relu"))
+    rounds = -(-items // 256)
+    big = WINOGRAD4 == 2 or (WINOGRAD4 and cin >= 16 and (items >= 2000 or 1000 <= items < 1600
+                                                            or (200 <= items <= 512 and items * 100 >= rounds * 256 * 84)))
+    big = big and not (pooled and (residual or act != "relu"))
     if big:
         return ("flop", 2.0 * n * cin * cout * 36 * (h * w / 16.0), "conv3x3_winograd4_kernel")
     return ("flop", 2.0 * n * cin * cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")

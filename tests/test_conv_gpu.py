@@ -58,11 +58,12 @@ def test_conv_matches_torch_cpu(n, cin, cout, h, w, ks, pad, act, device):
 
 
 BIG_CASES = [
-    # plain 3x3 layers with enough work items for the F(4x4,3x3) Winograd kernel (csrc/vfi_conv_winograd4.hip): 16x64 tiles
+    # 3x3 layers the F(4x4,3x3) Winograd kernel takes (csrc/vfi_conv_winograd4.hip: >= 2000 items of a 16x64 tile x 32 couts,
+    # Cin >= 16)
     # n, cin, cout, h, w, pad, act
-    (1, 8, 32, 512, 2048, "zeros", "relu"),       # exact tiles
-    (2, 10, 40, 250, 2044, "reflect", None),      # ragged tile rows / columns, Cin and Cout tails, two channel blocks
-    (1, 6, 64, 500, 1026, "zeros", "elu"),        # row length not a multiple of 4: element-wise stores
+    (1, 16, 32, 512, 2048, "zeros", "relu"),      # exact tiles
+    (2, 18, 40, 250, 2044, "reflect", None),      # ragged tile rows / columns, Cin and Cout tails, two channel blocks
+    (1, 17, 64, 500, 1026, "zeros", "elu"),       # row length not a multiple of 4: element-wise stores
 ]
 
 
@@ -83,7 +84,7 @@ def test_large_plain_conv_matches_torch_cpu(n, cin, cout, h, w, pad, act, device
 
 def test_large_conv_with_residual_matches_torch_cpu(device):
     # the residual variant of the F(4x4) Winograd kernel (PhaseNet blocks at full resolution): act(conv + b) + residual
-    n, cin, cout, h, w = 2, 12, 64, 270, 1920
+    n, cin, cout, h, w = 2, 16, 64, 270, 1920
     g = torch.Generator().manual_seed(5)
     x = torch.randn((n, cin, h, w), generator=g)
     res = torch.randn((n, cout, h, w), generator=g)
@@ -263,7 +264,7 @@ def test_winograd_conv_one_chunk_items_keep_their_bias(device):
                                                          (1, 32, 64, 37, 51, 3, False, "zeros"), (1, 512, 512, 8, 12, 3, False, "zeros"),
                                                          (1, 18, 32, 40, 72, 5, True, "reflect"),
                                                          # large enough for the F(4x4) Winograd kernel, ragged / odd sizes
-                                                         (1, 8, 32, 512, 2048, 3, False, "zeros"), (2, 6, 40, 251, 2046, 3, True, "reflect")])
+                                                         (1, 16, 32, 512, 2048, 3, False, "zeros"), (2, 18, 40, 251, 2046, 3, True, "reflect")])
 def test_conv_with_fused_pooling_equals_conv_then_pool(n, cin, cout, h, w, ks, is_max, pad, device):
     # vfi_conv2d_pool2: the pooled tensor written by the Winograd epilogue (3x3 ReLU layers in one piece), or by a pooling
     # pass behind split-K / direct layers -- bit-identical to conv2d followed by pool2 either way; odd sizes floor
