@@ -356,6 +356,52 @@ __device__ __forceinline__ void for_slots(int total, LoadF load, UseF use) {
     }
 }
 
+// A store whose address is (uniform plane descriptor, uniform byte offset, per-thread byte offset): the only vector
+// register of the address is the per-thread offset, which a pass never rewrites -- an ordinary store's 64-bit address
+// pair is recomputed per element, and rewriting it has to wait for the store before (see below).  Lanes that must not
+// store pass an offset of 0xffffffff (out of the descriptor's range: dropped).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ void plane_store(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, int uniform_bytes, float2 v) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 d;
+    d.x = __float_as_uint(v.x);
+    d.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_bytes, __builtin_amdgcn_readfirstlane(uniform_bytes), 0);
+}
+__device__ __forceinline__ void plane_store(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, int uniform_bytes, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_bytes, __builtin_amdgcn_readfirstlane(uniform_bytes), 0);
+}
+
+// Three-phase variants for passes that STORE to global memory.  On gfx950 a store keeps its address and data registers
+// until it has completed (the compiler guards them with s_waitcnt vmcnt, and vmcnt counts stores in order): a
+// compute -> store -> compute -> store sequence on the same registers waits for every store's round trip.  Here the
+// values of a whole chunk are formed first (`make`, into registers of their own) and stored afterwards (`put`), so a
+// chunk's stores go out back to back.
+template <typename LoadF, typename MakeF, typename PutF>
+__device__ __forceinline__ void for_slots(int total, LoadF load, MakeF make, PutF put) {
+    for (int q0 = 0; q0 * kThreads < total; q0 += kChunk) {      // (uniform trip count)
+        Slot v[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int e = (int)threadIdx.x + kThreads * (q0 + q);
+            if (kThreads * (q0 + q) < total) v[q] = load(e < total ? e : 0);
+        }
+        decltype(make(0, v[0])) o[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int e = (int)threadIdx.x + kThreads * (q0 + q);
+            if (kThreads * (q0 + q) < total) o[q] = make(e < total ? e : 0, v[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int e = (int)threadIdx.x + kThreads * (q0 + q);
+            if (e < total) put(e, o[q]);
+        }
+    }
+}
+
 // ---- structured slot walks: almost no per-element index arithmetic ---------------------------------------------------
 // Column tile (C = 1 << shift columns, h rows; line = column): thread t owns column cc = t & (C-1) and the rows
 // u = u0 + step*q (u0 = t >> shift, step = 256 >> shift).  The LDS index of (cc, u) is cc*pitch + phys(u) and
@@ -386,6 +432,38 @@ __device__ __forceinline__ void for_tile(int h, int shift, int pitch, LoadF load
         }
     }
 }
+//   make(u, uq, cc, lds_index, slot) -> Out ; put(u, uq, cc, out)      (storing passes, see for_slots)
+template <typename LoadF, typename MakeF, typename PutF>
+__device__ __forceinline__ void for_tile(int h, int shift, int pitch, LoadF load, MakeF make, PutF put) {
+    const int t = threadIdx.x, cc = t & ((1 << shift) - 1), u0 = t >> shift, step = kThreads >> shift;
+    const int lbase = mul24(cc, pitch) + phys(u0);
+    const int nq = (h - 1) / step + 1;                            // (uniform) slots per thread
+    for (int q0 = 0; q0 < nq; q0 += kChunk) {
+        Slot v[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (q0 + q < nq) {
+                const int uq = step * (q0 + q), u = u0 + uq;
+                v[q] = load(u < h ? u : u0, u < h ? uq : 0, cc);
+            }
+        }
+        decltype(make(0, 0, 0, 0, v[0])) o[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (q0 + q < nq) {
+                const int uq = step * (q0 + q), u = u0 + uq;
+                o[q] = make(u < h ? u : u0, u < h ? uq : 0, cc, u < h ? lbase + uq + (uq >> 5) : lbase, v[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (q0 + q < nq) {
+                const int uq = step * (q0 + q), u = u0 + uq;
+                if (u < h) put(u, uq, cc, o[q]);
+            }
+        }
+    }
+}
 // Rows (`lines` rows of n >= 256 elements; line = row): thread t owns the columns j = t + 256*qq of every row.
 // phys(t + 256*qq) = phys(t) + 264*qq, so the LDS index is phys(t) + (l*pitch + 264*qq), the bracket uniform.
 //   load(l, j, jq) -> Slot           (jq = 256*qq uniform; j = t + jq)
@@ -408,6 +486,38 @@ __device__ __forceinline__ void for_rows(int lines, int n, int pitch, LoadF load
             if (s0 + q < ns) {
                 const int l = (s0 + q) / qn, qq = (s0 + q) - l * qn, jq = kThreads * qq, j = t + jq;
                 if (j < n) use(l, j, jq, pt + (l * pitch + (kThreads + kThreads / 32) * qq), v[q]);
+            }
+        }
+    }
+}
+
+//   make(l, j, jq, lds_index, slot) -> Out ; put(l, j, jq, out)        (storing passes, see for_slots)
+template <typename LoadF, typename MakeF, typename PutF>
+__device__ __forceinline__ void for_rows(int lines, int n, int pitch, LoadF load, MakeF make, PutF put) {
+    const int t = threadIdx.x, pt = phys(t);
+    const int qn = (n - 1) / kThreads + 1, ns = lines * qn;       // (uniform)
+    for (int s0 = 0; s0 < ns; s0 += kChunk) {
+        Slot v[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (s0 + q < ns) {
+                const int l = (s0 + q) / qn, qq = (s0 + q) - l * qn, jq = kThreads * qq, j = t + jq;
+                v[q] = load(l, j < n ? j : 0, j < n ? jq : -t);
+            }
+        }
+        decltype(make(0, 0, 0, 0, v[0])) o[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (s0 + q < ns) {
+                const int l = (s0 + q) / qn, qq = (s0 + q) - l * qn, jq = kThreads * qq, j = t + jq;
+                o[q] = make(l, j < n ? j : 0, j < n ? jq : -t, j < n ? pt + (l * pitch + (kThreads + kThreads / 32) * qq) : pt + l * pitch, v[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (s0 + q < ns) {
+                const int l = (s0 + q) / qn, qq = (s0 + q) - l * qn, jq = kThreads * qq, j = t + jq;
+                if (j < n) put(l, j, jq, o[q]);
             }
         }
     }

@@ -545,16 +545,16 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_level_cols_kerne
         fft_lines(buf, BP > 1 ? BP * C : lines, pitch, a.ph, twl);
       for (int bb = 0; bb < BP; ++bb) {
         const float2 *bufb = buf + mul24(bb * C, pitch);
-        float2 *Tb = a.T + ((size_t)n * NB + b0 + bb) * hw;
+        const __amdgpu_buffer_rsrc_t Tr = plane_rsrc(a.T + ((size_t)n * NB + b0 + bb) * hw, hw * sizeof(float2));
+        const unsigned tlane = ccok ? (unsigned)tb * 8u : 0xffffffffu;
         for_tile(h, shift, pitch,
                  [&](int u, int, int) {
                      Slot s;
                      if (blu) s.c = a.ph.chirp[u];
                      return s;
                  },
-                 [&](int, int uq, int, int idx, const Slot &s) {
-                     if (ccok) Tb[tb + mul24(uq, w)] = store_value<true>(bufb[idx], s.c, blu);
-                 });
+                 [&](int, int, int, int idx, const Slot &s) { return store_value<true>(bufb[idx], s.c, blu); },
+                 [&](int, int uq, int, const float2 &o) { plane_store(Tr, tlane, mul24(uq, w) * 8, o); });
       }
         lds_barrier();
     }
