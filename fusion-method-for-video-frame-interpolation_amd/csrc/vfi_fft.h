@@ -392,7 +392,7 @@ __device__ __forceinline__ void for_slots(int total, LoadF load, MakeF make, Put
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
             const int e = (int)threadIdx.x + kThreads * (q0 + q);
-            if (kThreads * (q0 + q) < total) o[q] = make(e < total ? e : 0, v[q]);
+            if (e < total) o[q] = make(e, v[q]);
         }
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
@@ -452,7 +452,7 @@ __device__ __forceinline__ void for_tile(int h, int shift, int pitch, LoadF load
         for (int q = 0; q < kChunk; ++q) {
             if (q0 + q < nq) {
                 const int uq = step * (q0 + q), u = u0 + uq;
-                o[q] = make(u < h ? u : u0, u < h ? uq : 0, cc, u < h ? lbase + uq + (uq >> 5) : lbase, v[q]);
+                if (u < h) o[q] = make(u, uq, cc, lbase + uq + (uq >> 5), v[q]);
             }
         }
 #pragma unroll
@@ -510,7 +510,7 @@ __device__ __forceinline__ void for_rows(int lines, int n, int pitch, LoadF load
         for (int q = 0; q < kChunk; ++q) {
             if (s0 + q < ns) {
                 const int l = (s0 + q) / qn, qq = (s0 + q) - l * qn, jq = kThreads * qq, j = t + jq;
-                o[q] = make(l, j < n ? j : 0, j < n ? jq : -t, j < n ? pt + (l * pitch + (kThreads + kThreads / 32) * qq) : pt + l * pitch, v[q]);
+                if (j < n) o[q] = make(l, j, jq, pt + (l * pitch + (kThreads + kThreads / 32) * qq), v[q]);
             }
         }
 #pragma unroll
