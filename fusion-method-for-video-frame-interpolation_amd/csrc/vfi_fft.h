@@ -356,10 +356,9 @@ __device__ __forceinline__ void for_slots(int total, LoadF load, UseF use) {
     }
 }
 
-// A store whose address is (uniform plane descriptor, uniform byte offset, per-thread byte offset): the only vector
-// register of the address is the per-thread offset, which a pass never rewrites -- an ordinary store's 64-bit address
-// pair is recomputed per element, and rewriting it has to wait for the store before (see below).  Lanes that must not
-// store pass an offset of 0xffffffff (out of the descriptor's range: dropped).
+// A store whose address is (uniform plane descriptor, uniform byte offset, per-thread byte offset): no 64-bit address
+// arithmetic per element, and lanes that must not store pass an offset of 0xffffffff (out of the descriptor's range:
+// dropped) instead of branching around the store.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *base, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
 }
@@ -374,11 +373,11 @@ __device__ __forceinline__ void plane_store(__amdgpu_buffer_rsrc_t r, unsigned l
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_bytes, __builtin_amdgcn_readfirstlane(uniform_bytes), 0);
 }
 
-// Three-phase variants for passes that STORE to global memory.  On gfx950 a store keeps its address and data registers
-// until it has completed (the compiler guards them with s_waitcnt vmcnt, and vmcnt counts stores in order): a
-// compute -> store -> compute -> store sequence on the same registers waits for every store's round trip.  Here the
-// values of a whole chunk are formed first (`make`, into registers of their own) and stored afterwards (`put`), so a
-// chunk's stores go out back to back.
+// Three-phase variants for passes that STORE to global memory.  On gfx950 vmcnt counts loads and stores together, in
+// order: a value that depends on a (conditional) load of the chunk -- a Bluestein chirp factor, a mask -- makes the compiler
+// put `s_waitcnt vmcnt(0)` in front of every element's arithmetic, and once the first stores of the chunk are out, that
+// wait sits out their round trips one by one.  Here the values of a whole chunk are formed first (`make`) and stored
+// afterwards (`put`): the loads are consumed before the first store is issued and the chunk's stores go out back to back.
 template <typename LoadF, typename MakeF, typename PutF>
 __device__ __forceinline__ void for_slots(int total, LoadF load, MakeF make, PutF put) {
     for (int q0 = 0; q0 * kThreads < total; q0 += kChunk) {      // (uniform trip count)
