@@ -426,7 +426,11 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles) {
     return (b & 7) * per + (b >> 3);
 }
 
-template <bool FIRST, int NB>
+// BLU: the transform length goes through Bluestein (chirp factors in the fill / drain).  A compile-time constant: with a
+// run-time flag every fill / drain carries conditional chirp loads, and the compiler then waits for ALL outstanding
+// memory operations (vmcnt(0): loads and stores share the counter) in front of every element -- also on the smooth
+// levels, the large ones, that never load a chirp factor.
+template <bool FIRST, int NB, bool BLU>
 __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_level_cols_kernel(const LevelColsArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_level_cols_kerne
     const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);
     const int v0 = tile * C, lines = w - v0 < C ? w - v0 : C;
     const int shift = __ffs(C) - 1, total = h * C, wh = w / 2 + 1;
-    const bool blu = a.ph.bluestein != 0;
+    constexpr bool blu = BLU;
     const size_t hw = (size_t)h * w;
     const float2 *srcn = a.src + (FIRST ? (size_t)n * h * wh : (size_t)n * hw);      // (32-bit offsets inside a plane)
     auto load_z = [&](int u, int v) -> float2 {          // this level's low-pass spectrum at (u, v)
@@ -592,7 +596,7 @@ __device__ __forceinline__ void zero_row_padding(float2 *buf, int lines, int pit
 }
 
 // rows of T -> inverse row FFT -> (phase, amplitude) or the complex coefficient (coeff_to_values, src/train/pyramid.py:63-69)
-template <int NB>
+template <int NB, bool BLU>
 __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_polar_kernel(const RowsPolarArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_polar_kerne
     line_bases(base, lines, row0, a.h, w, a.pm, NB);
     const int total = lines * w;
     const float inv_w = 1.0f / (float)w;
-    const bool blu = a.pw.bluestein != 0;
+    constexpr bool blu = BLU;
     const float2 *Trow = a.T + row0 * w;
     auto fill_load = [&](int l, int j) {
         Slot s;
@@ -676,7 +680,7 @@ __global__ void pyr_amp_max_finish_kernel(const unsigned *__restrict__ bits, flo
 
 // (phase, amplitude) rows -> complex -> forward row FFT -> T (values_to_coeff, src/train/pyramid.py:99-107, + the row half of
 // reconstruct's fft2)
-template <int NB>
+template <int NB, bool BLU>
 __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_from_polar_kernel(const RowsPolarArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_from_polar_
     lds_barrier();
     const int total = lines * w;
     const float inv_w = 1.0f / (float)w;
-    const bool blu = a.pw.bluestein != 0;
+    constexpr bool blu = BLU;
     auto fill_load = [&](int l, int j) {
         const size_t o = base[l] + j;
         Slot s;
@@ -747,7 +751,7 @@ struct CombineColsArgs {
 };
 
 // cur = sum_b (-i) * FFTcol(T_b) * P_s[b]  +  embed(res * lomask)     (reconstruct: orientdft + resdft)
-template <int NB>
+template <int NB, bool BLU>
 __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_combine_cols_kernel(const CombineColsArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_combine_cols_ker
     const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);
     const int v0 = tile * C, lines = w - v0 < C ? w - v0 : C;
     const int shift = __ffs(C) - 1;
-    const bool blu = a.ph.bluestein != 0;
+    constexpr bool blu = BLU;
     const size_t hw = (size_t)h * w;
     float2 *cur = a.cur + (size_t)n * hw;
     const int BP = a.bands_per_pass;
@@ -1101,21 +1105,26 @@ static int pyr_analyze_impl(vfi_pyr_plan *p, const float *img, int N, float *hig
                          p->lo0, p->hi0, L.h, L.w, h2, w2, tile, bpp, 1.0f / ((float)H * (float)W)};
         const dim3 cgrid(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N);
         const size_t clds = level_lds_bytes(ph, tile, bpp);
-        if (k == 0) {
-            allow_big_lds(pyr_level_cols_kernel<true, 4>);
-            hipLaunchKernelGGL((pyr_level_cols_kernel<true, 4>), cgrid, dim3(kThreads), clds, s, ca);
-        } else {
-            allow_big_lds(pyr_level_cols_kernel<false, 4>);
-            hipLaunchKernelGGL((pyr_level_cols_kernel<false, 4>), cgrid, dim3(kThreads), clds, s, ca);
-        }
+#define VFI_LAUNCH_COLS(FIRST, BLU)                              \
+    allow_big_lds(pyr_level_cols_kernel<FIRST, 4, BLU>);         \
+    hipLaunchKernelGGL((pyr_level_cols_kernel<FIRST, 4, BLU>), cgrid, dim3(kThreads), clds, s, ca)
+        if (k == 0) { if (ph.bluestein) { VFI_LAUNCH_COLS(true, true); } else { VFI_LAUNCH_COLS(true, false); } }
+        else { if (ph.bluestein) { VFI_LAUNCH_COLS(false, true); } else { VFI_LAUNCH_COLS(false, false); } }
+#undef VFI_LAUNCH_COLS
         const long long rows = (long long)N * nb * L.h;
         int lines = rows_per_group(pw, rows);
         if (lines > 256) lines = 256;
         RowsPolarArgs ra{pw, p->bands, phase[k], amp ? amp[k] : nullptr, make_map(plane_index, k, N, nb, flags), rows, L.h, lines,
                          1.0f / ((float)L.h * (float)L.w), phase_scale, amp_max ? p->amp_bits + (size_t)k * groups : nullptr, groups};
-        allow_big_lds(pyr_rows_polar_kernel<4>);
-        hipLaunchKernelGGL((pyr_rows_polar_kernel<4>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
-                           row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        if (pw.bluestein) {
+            allow_big_lds(pyr_rows_polar_kernel<4, true>);
+            hipLaunchKernelGGL((pyr_rows_polar_kernel<4, true>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                               row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        } else {
+            allow_big_lds(pyr_rows_polar_kernel<4, false>);
+            hipLaunchKernelGGL((pyr_rows_polar_kernel<4, false>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                               row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        }
         src = next;
     }
     if (low) {  // low residual: real(ifft2(lodft))
@@ -1187,15 +1196,27 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
         if (lines > 256) lines = 256;
         RowsPolarArgs ra{pw, p->bands, const_cast<float *>(phase[k]), amp ? const_cast<float *>(amp[k]) : nullptr,
                          make_map(plane_index, k, N, nb, flags), rows, L.h, lines, 1.0f, 1.0f, nullptr, 1};
-        allow_big_lds(pyr_rows_from_polar_kernel<4>);
-        hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
-                           row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        if (pw.bluestein) {
+            allow_big_lds(pyr_rows_from_polar_kernel<4, true>);
+            hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4, true>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                               row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        } else {
+            allow_big_lds(pyr_rows_from_polar_kernel<4, false>);
+            hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4, false>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                               row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        }
         int tile, bpp;
         level_tiling(ph, L.w, &tile, &bpp);
         CombineColsArgs ca{ph, p->bands, res, cur, L.P_s, L.lomask, L.h, L.w, h2, w2, tile, bpp};
-        allow_big_lds(pyr_combine_cols_kernel<4>);
-        hipLaunchKernelGGL((pyr_combine_cols_kernel<4>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
-                           level_lds_bytes(ph, tile, bpp), s, ca);
+        if (ph.bluestein) {
+            allow_big_lds(pyr_combine_cols_kernel<4, true>);
+            hipLaunchKernelGGL((pyr_combine_cols_kernel<4, true>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
+                               level_lds_bytes(ph, tile, bpp), s, ca);
+        } else {
+            allow_big_lds(pyr_combine_cols_kernel<4, false>);
+            hipLaunchKernelGGL((pyr_combine_cols_kernel<4, false>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
+                               level_lds_bytes(ph, tile, bpp), s, ca);
+        }
         res = cur;
     }
     const float2 *hi_half = nullptr;
