@@ -1,5 +1,10 @@
 """GPU parity of the fp32-MFMA convolution (through the C ABI) against a plain PyTorch fp32
 CPU reference of the same op (the op the oracle networks are built from)."""
+import os
+import re
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -80,6 +85,19 @@ def test_large_plain_conv_matches_torch_cpu(n, cin, cout, h, w, pad, act, device
     err = (out.cpu().double() - ref).abs()
     # the larger Winograd tile costs about a decimal digit: rms 2e-6, maximum 3e-5 of the output rms
     assert err.max().item() <= 1e-4 and err.pow(2).mean().sqrt().item() <= 5e-6, (err.max().item(), err.pow(2).mean().sqrt().item())
+
+
+def test_f4x4_kernel_on_small_and_ragged_shapes(device):
+    # VFI_CONV_WINOGRAD4=2 sends EVERY 3x3 layer through the F(4x4) kernel (the library reads the switch once per process,
+    # hence the child process): 60 random shapes -- tiles on both image borders, partial tiles, Cin / Cout tails,
+    # zero / reflect padding, residuals, all activations -- against float64 (tools/fuzz_conv.py)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VFI_CONV_WINOGRAD4="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_conv.py"), "17", "60"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"worst abs error ([0-9.e+-]+)", r.stdout)
+    assert m and float(m.group(1)) <= 1e-4, r.stdout[-2000:]
 
 
 def test_large_conv_with_residual_matches_torch_cpu(device):

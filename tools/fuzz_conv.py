@@ -30,6 +30,6 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
     torch.cuda.synchronize()
     err = (out.cpu().double() - ref).abs().max().item()
     worst = max(worst, err)
-    if err > 5e-5 or not torch.isfinite(out).all():
+    if err > 1e-4 or not torch.isfinite(out).all():
         print("FAIL", (n, cin, cout, h, w, pad, act, use_res), err)
 print("cases done, worst abs error", worst)
