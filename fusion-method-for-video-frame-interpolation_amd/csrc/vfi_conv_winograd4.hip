@@ -49,7 +49,7 @@ struct Wino4Tile {
     static constexpr int NPOS = 36, NGRP = NPOS / 4;
     static constexpr int W_FLOATS = CK * NPOS * BN;       // 4608 = 18 wave-instructions
     static constexpr int W_WI = W_FLOATS / 256;
-    static constexpr int W_INSTR = (W_WI + WAVES - 1) / WAVES;                      // 3 (waves 2..7: 2)
+    static constexpr int W_INSTR = (W_WI + WAVES - 1) / WAVES;                      // 3 (see weight_piece)
     static constexpr int BUF = IN_FLOATS + W_FLOATS;      // 38 KiB
     static constexpr int NBUF = 4;
     static constexpr int BIAS_SLOTS = 8;                  // (> NBUF: the DMA cursor runs up to NBUF one-chunk items ahead)
@@ -68,6 +68,15 @@ __device__ __forceinline__ const char *uni(const char *p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+}
+
+// Which 1 KiB piece of a chunk's 18 KiB weight slab wave `wave` requests as its t-th (t < 3), or -1.  The 20 input pieces
+// go 3 to each of waves 0..3 and 2 to waves 4..7, so the weight pieces go mostly to the upper waves: 5 | 4 | 5 requests
+// per chunk for waves 0,1 | 2,3 | 4..7 (a request holds its wave for ~65 cycles and the chunk's barrier waits for the
+// slowest wave: 3 + 3 on waves 0,1 would cost everyone one more).
+__device__ __forceinline__ int weight_piece(int wave, int t) {
+    if (wave >= 4) return (wave - 4) + 4 * t;                 // 0 .. 11
+    return t == 0 ? 12 + wave : (t == 1 && wave < 2 ? 16 + wave : -1);
 }
 
 struct Item {
@@ -182,8 +191,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
         }
 #pragma unroll
         for (int t = 0; t < T::W_INSTR; ++t) {
-            const int f = 64 * (wave + T::WAVES * t) + lane;         // float4 inside the slab [4 cin][9 groups][32 cout][4]
-            woff[t] = (unsigned)(((f / T::BN) * a.Cout_pad + it.nb * T::BN + f % T::BN) * 16);      // (issued only for f < W_FLOATS / 4)
+            const int wp = weight_piece(wave, t);
+            const int f = 64 * (wp < 0 ? 0 : wp) + lane;             // float4 inside the slab [4 cin][9 groups][32 cout][4]
+            woff[t] = (unsigned)(((f / T::BN) * a.Cout_pad + it.nb * T::BN + f % T::BN) * 16);      // (issued only for wp >= 0)
         }
     };
     // The DMA requests of the next chunk of this workgroup's item sequence into ring slot `slot`.  One workgroup per CU
@@ -227,9 +237,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
             }
         } else {
             const int t = k - T::IN_X4;
-            if (uni(wave) + T::WAVES * t < T::W_WI) {
+            const int wp = weight_piece(uni(wave), t);
+            if (wp >= 0) {
                 const __amdgpu_buffer_rsrc_t rw = make_rsrc(uni(w_ptr), d.live ? w_chunk_bytes : 0u);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(d.buf + T::IN_FLOATS + 256 * (wave + T::WAVES * t)),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(d.buf + T::IN_FLOATS + 256 * wp),
                                                          16, woff[t], 0, 0, 0);
             }
         }
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
     Item it = decode_item(a, cL);
     int ch = 0, slot = 0, cseq = 0;
     zero_acc();
-    // Interior requests per wave and chunk: waves 0,1: 3 + 3, waves 2,3: 3 + 2, waves 4..7: 2 + 2 (border tiles: more; an
+    // Interior requests per wave and chunk: waves 0,1: 3 + 2, waves 2,3: 3 + 1, waves 4..7: 2 + 3 (border tiles: more; an
     // item's stores in between only make a counted wait earlier).
     static_assert(T::NBUF == 4 && T::IN_WI == 20 && T::W_WI == 18, "update the counted waits");
     auto read_patch = [&](float (&d)[6][6], int sl) __attribute__((always_inline)) {       // this lane's raw 6x6 patch
@@ -286,8 +297,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
         }
     };
     float t[6][6];          // the current chunk's patch, fetched at the end of the chunk before; B^T d in place
-    if (wave < 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // chunk 0 landed (chunks 1, 2 may be in flight)
-    else if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if (wave < 2 || wave >= 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");       // chunk 0 landed (chunks 1, 2 may be in flight)
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -296,8 +306,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
         // Chunk c+1 (whose patch is fetched at the end of this chunk) has landed once only the requests of chunk c+2 are
         // outstanding; the barrier makes every wave's part visible and retires everyone's reads of chunk c-1, whose slot the
         // requests of chunk c+3 then take.
-        if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (wave < 2 || wave >= 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
