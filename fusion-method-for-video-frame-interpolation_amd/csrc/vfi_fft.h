@@ -155,6 +155,14 @@ template <> struct Cis<9> {
         return make_float2(t[e][0], t[e][1]);
     }
 };
+template <> struct Cis<12> {
+    static VFI_HD float2 at(int e) {
+        constexpr float h = 0.86602540378443864676f;
+        constexpr float t[12][2] = {{1.0f, 0.0f}, {h, 0.5f}, {0.5f, h}, {0.0f, 1.0f}, {-0.5f, h}, {-h, 0.5f},
+                                    {-1.0f, 0.0f}, {-h, -0.5f}, {-0.5f, -h}, {0.0f, -1.0f}, {0.5f, -h}, {h, -0.5f}};
+        return make_float2(t[e][0], t[e][1]);
+    }
+};
 template <> struct Cis<15> {
     static VFI_HD float2 at(int e) {
         constexpr float t[15][2] = {{1.0f, 0.0f}, {0.91354545764260086660f, 0.40673664307580015276f}, {0.66913060635885823757f, 0.74314482547739413310f},
@@ -196,6 +204,7 @@ template <int R1, int R2, bool INV> struct DftComposite {
     }
 };
 template <bool INV> struct Dft<9, INV> { static VFI_HD void run(float2 *v) { DftComposite<3, 3, INV>::run(v); } };
+template <bool INV> struct Dft<12, INV> { static VFI_HD void run(float2 *v) { DftComposite<3, 4, INV>::run(v); } };
 template <bool INV> struct Dft<15, INV> { static VFI_HD void run(float2 *v) { DftComposite<3, 5, INV>::run(v); } };
 
 // exact floor(t / d) for 0 <= t < 2^15, 1 <= d < 2^15 through a float reciprocal (the distance of (t + 0.5) / d from
@@ -291,10 +300,8 @@ VFI_HD void stage_gather(StageRegs<R> &s, const Team tm, const float2 *buf, int 
                 if (R > 3) wr[3] = cmul(wr[1], wr[2]);
                 if (R > 5) wr[5] = cmul(wr[4], wr[1]);
                 if (R > 6) { wr[6] = cmul(wr[4], wr[2]); wr[7] = cmul(wr[4], wr[3]); }
-                if (R > 9) {
-                    wr[9] = cmul(wr[8], wr[1]); wr[10] = cmul(wr[8], wr[2]); wr[11] = cmul(wr[8], wr[3]); wr[12] = cmul(wr[8], wr[4]);
-                    wr[13] = cmul(wr[8], wr[5]); wr[14] = cmul(wr[8], wr[6]);
-                }
+                if (R > 9) { wr[9] = cmul(wr[8], wr[1]); wr[10] = cmul(wr[8], wr[2]); wr[11] = cmul(wr[8], wr[3]); }
+                if (R > 12) { wr[12] = cmul(wr[8], wr[4]); wr[13] = cmul(wr[8], wr[5]); wr[14] = cmul(wr[8], wr[6]); }
                 if (R > 15) wr[15] = cmul(wr[8], wr[7]);
 #pragma unroll
                 for (int r = 1; r < R; ++r) s.v[q][r] = cmul(s.v[q][r], wr[r]);
@@ -555,6 +562,7 @@ __device__ __forceinline__ void stage_any(int R, float2 *buf, int lines, int pit
     switch (R) {
         case 16: stage<16, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
         case 15: stage<15, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
+        case 12: stage<12, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
         case 9: stage<9, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
         case 8: stage<8, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
         case 4: stage<4, false>(buf, lines, pitch, m, p, tw, tw_len, nullptr, wp); break;
@@ -592,7 +600,7 @@ __device__ __forceinline__ void fft_lines(float2 *buf, int lines, int pitch, con
         p *= pl.radix[s];
     }
     if (pl.bluestein) {
-        switch (pl.radix[0]) {                  // (a Bluestein length is a power of two: radices 16, 8, 4, 2 only)
+        switch (pl.radix[0]) {                  // (a Bluestein length is 2^k or 3 * 2^k, powers of two first: 16, 8, 4, 2 only)
             case 16: stage<16, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt, wp); break;
             case 8: stage<8, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt, wp); break;
             case 4: stage<4, true>(buf, lines, pitch, pl.m, 1, twl, pl.tw_len, pl.bfilt, wp); break;
@@ -630,10 +638,22 @@ inline int min_twiddle_entries(const Plan1D &pl) {
     for (int s = 1; s < pl.nstages; ++s) need = pl.m / pl.radix[s] > need ? pl.m / pl.radix[s] : need;
     return need;
 }
+// Bluestein's convolution length: the smallest of 2^k and 3 * 2^k (k >= 1) that holds 2n - 1 points -- three quarters of
+// the next power of two when that is enough, at the same number of stages (factor_bluestein).
 inline int bluestein_length(int n) {
     int M = 1;
     while (M < 2 * n - 1) M *= 2;
-    return M;
+    return (M >= 32 && M / 4 * 3 >= 2 * n - 1) ? M / 4 * 3 : M;
+}
+// radices of a Bluestein length: the power-of-two stages first (the spectral product sits in the first stage, which the
+// engine instantiates for radices 16, 8, 4, 2), one radix-12 stage last for 3 * 2^k
+inline bool factor_bluestein(int m, int *radix, int *nstages) {
+    if (m % 3) return factor_smooth(m, radix, nstages);
+    if (m % 12 || m / 12 < 2 || !factor_smooth(m / 12, radix, nstages) || *nstages >= kMaxStages) return false;
+    for (int i = 0; i < *nstages; ++i)
+        if (radix[i] != 16 && radix[i] != 8 && radix[i] != 4 && radix[i] != 2) return false;
+    radix[(*nstages)++] = 12;
+    return true;
 }
 // LDS line pitch: row passes store lines back to back; column passes fill `tile` lines with consecutive lanes going
 // ACROSS the lines, so the pitch is chosen = 32/tile (mod 32) elements: the lanes of one wave then cover all banks

@@ -41,6 +41,22 @@ void host_fft_pow2(std::vector<cd> &a) {       // in-place radix-2, forward, dou
     }
 }
 
+// ... of 2^k or 3 * 2^k points: three interleaved power-of-two transforms and one radix-3 step
+void host_fft_bluestein(std::vector<cd> &a) {
+    const size_t m = a.size();
+    if (m % 3) return host_fft_pow2(a);
+    const size_t q = m / 3;
+    std::vector<cd> f[3] = {std::vector<cd>(q), std::vector<cd>(q), std::vector<cd>(q)};
+    for (size_t j = 0; j < q; ++j)
+        for (int r = 0; r < 3; ++r) f[r][j] = a[3 * j + r];
+    for (int r = 0; r < 3; ++r) host_fft_pow2(f[r]);
+    for (size_t k = 0; k < m; ++k) {
+        cd acc(0.0, 0.0);
+        for (int r = 0; r < 3; ++r) acc += f[r][k % q] * std::polar(1.0, -2.0 * kPi * (double)((r * k) % m) / (double)m);
+        a[k] = acc;
+    }
+}
+
 template <int LOAD, int STORE, bool INV>
 __global__ __launch_bounds__(kThreads, kThreads / 128) void fft_rows_kernel(const RowArgs a) {
     extern __shared__ float2 buf[];
@@ -182,7 +198,7 @@ int make_plan(int n, Plan1D *out, void (*own)(void *ctx, void *dev), void *ctx) 
     pl.m = pl.bluestein ? bluestein_length(n) : n;
     pl.tw_len = twiddle_entries(pl.m);
     if (pl.m > kMaxElems) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d needs %d LDS elements (max %d)", n, pl.m, kMaxElems);
-    if (pl.bluestein && !factor_smooth(pl.m, pl.radix, &pl.nstages)) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d", n);
+    if (pl.bluestein && !factor_bluestein(pl.m, pl.radix, &pl.nstages)) return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d", n);
     if (pl.tw_len < min_twiddle_entries(pl)) pl.tw_len = min_twiddle_entries(pl);
     if (max_lines(pl) < 1)       // one line + its twiddle table must fit a workgroup's LDS budget (non-smooth lengths above 2048)
         return vfi::fail(VFI_ERR_UNSUPPORTED, "FFT length %d (transformed as %d points) exceeds the LDS budget of the engine", n, pl.m);
@@ -206,7 +222,7 @@ int make_plan(int n, Plan1D *out, void (*own)(void *ctx, void *dev), void *ctx) 
         for (int j = 0; j < n; ++j) w[j] = std::polar(1.0, -kPi * (double)(((long long)j * j) % (2LL * n)) / (double)n);
         b[0] = std::conj(w[0]);
         for (int j = 1; j < n; ++j) b[j] = b[pl.m - j] = std::conj(w[j]);
-        host_fft_pow2(b);
+        host_fft_bluestein(b);
         for (auto &v : b) v /= (double)pl.m;
         if ((rc = upload(w, &pl.chirp)) || (rc = upload(b, &pl.bfilt))) return rc;
     }

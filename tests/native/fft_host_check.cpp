@@ -23,7 +23,7 @@ static void build(HostPlan &hp, int n) {
     pl.bluestein = !factor_smooth(n, pl.radix, &pl.nstages);
     pl.m = pl.bluestein ? bluestein_length(n) : n;
     pl.tw_len = twiddle_entries(pl.m);
-    if (pl.bluestein && !factor_smooth(pl.m, pl.radix, &pl.nstages)) { std::printf("plan failed for %d\n", n); std::exit(2); }
+    if (pl.bluestein && !factor_bluestein(pl.m, pl.radix, &pl.nstages)) { std::printf("plan failed for %d\n", n); std::exit(2); }
     if (pl.tw_len < min_twiddle_entries(pl)) pl.tw_len = min_twiddle_entries(pl);
     hp.tw.resize(pl.m);
     for (int k = 0; k < pl.m; ++k) hp.tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / pl.m), (float)std::sin(-2.0 * M_PI * k / pl.m));
@@ -64,6 +64,7 @@ static void host_stage_any(int R, float2 *buf, int lines, int pitch, int m, int 
     switch (R) {
         case 16: host_stage<16, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt, wave); break;
         case 15: host_stage<15, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt, wave); break;
+        case 12: host_stage<12, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt, wave); break;
         case 9: host_stage<9, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt, wave); break;
         case 8: host_stage<8, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt, wave); break;
         case 4: host_stage<4, MULB>(buf, lines, pitch, m, p, tw, tw_len, bfilt, wave); break;
