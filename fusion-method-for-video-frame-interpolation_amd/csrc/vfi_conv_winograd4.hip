@@ -206,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
         float *buf;
         bool live, x4;
     };
+    __amdgpu_buffer_rsrc_t rin_c = make_rsrc(a.x, 0u), rw_c = make_rsrc(a.wp, 0u);     // this chunk's descriptors (dma_begin)
     auto dma_begin = [&](int slot) __attribute__((always_inline)) {
         float *b = lds + uni(slot) * T::BUF;
         const bool live = uni(iL) < Ltotal, border = live && uni(iborder ? 1 : 0) != 0;
@@ -226,21 +227,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_winograd4_kernel(const ConvArg
                                                      4, ln < (unsigned)T::BN ? ((unsigned)uni(inb) * T::BN + ln) * 4u : 0xffffffffu, 0, 0, 0);
         }
         ifirst = false;
+        rin_c = make_rsrc(uni(in_ptr), live ? (unsigned)uni((int)in_bytes_left) : 0u);
+        rw_c = make_rsrc(uni(w_ptr), live ? w_chunk_bytes : 0u);
         return Dma{b, live, !border};
     };
     auto dma_piece = [&](const Dma &d, int k) __attribute__((always_inline)) {      // k = 0 .. 5 (a constant after unrolling)
         if (k < T::IN_X4) {
             if (d.x4 && uni(wave) + T::WAVES * k < T::IN_WI) {
-                const __amdgpu_buffer_rsrc_t rin = make_rsrc(uni(in_ptr), d.live ? (unsigned)uni((int)in_bytes_left) : 0u);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(d.buf + 256 * (wave + T::WAVES * k)),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin_c, (__attribute__((address_space(3))) void *)(d.buf + 256 * (wave + T::WAVES * k)),
                                                          16, voff[k], 0, 0, 0);
             }
         } else {
             const int t = k - T::IN_X4;
             const int wp = weight_piece(uni(wave), t);
             if (wp >= 0) {
-                const __amdgpu_buffer_rsrc_t rw = make_rsrc(uni(w_ptr), d.live ? w_chunk_bytes : 0u);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(d.buf + T::IN_FLOATS + 256 * wp),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_c, (__attribute__((address_space(3))) void *)(d.buf + T::IN_FLOATS + 256 * wp),
                                                          16, woff[t], 0, 0, 0);
             }
         }
