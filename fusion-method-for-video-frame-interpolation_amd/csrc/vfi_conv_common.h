@@ -25,6 +25,17 @@ __host__ __device__ __forceinline__ int fast_div(int n, const FastDiv &f) {
     return (int)((t + (((unsigned)n - t) >> f.sh1)) >> f.sh2);
 }
 
+// F(4x4) Winograd kernel (vfi_conv_winograd4.hip; declared here so that tests/native/fastdiv_check.cpp can count the
+// requests the kernel's hand-written `s_waitcnt vmcnt` constants assume).  Which 1 KiB piece of a chunk's 18 KiB weight
+// slab wave `wave` requests as its t-th (t < 3), or -1.  The 20 input pieces go 3 to each of waves 0..3 and 2 to waves
+// 4..7 (piece w + 8k of wave w), so the weight pieces go mostly to the upper waves: 5 | 4 | 5 requests per chunk for
+// waves 0,1 | 2,3 | 4..7 (a request holds its wave for 36-70 cycles and the chunk's barrier waits for the slowest wave:
+// 3 + 3 on waves 0,1 would cost everyone one more).
+__host__ __device__ __forceinline__ int weight_piece(int wave, int t) {
+    if (wave >= 4) return (wave - 4) + 4 * t;                 // 0 .. 11
+    return t == 0 ? 12 + wave : (t == 1 && wave < 2 ? 16 + wave : -1);
+}
+
 struct ConvArgs {
     const float *x;      // (N, Cin, H, W) slice, batch stride x_bs
     const float *wp;     // packed weights [Cin_pad][KS*KS][Cout_pad]

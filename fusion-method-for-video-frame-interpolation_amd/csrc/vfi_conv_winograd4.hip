@@ -70,15 +70,6 @@ __device__ __forceinline__ const char *uni(const char *p) {
     return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
 }
 
-// Which 1 KiB piece of a chunk's 18 KiB weight slab wave `wave` requests as its t-th (t < 3), or -1.  The 20 input pieces
-// go 3 to each of waves 0..3 and 2 to waves 4..7, so the weight pieces go mostly to the upper waves: 5 | 4 | 5 requests
-// per chunk for waves 0,1 | 2,3 | 4..7 (a request holds its wave for ~65 cycles and the chunk's barrier waits for the
-// slowest wave: 3 + 3 on waves 0,1 would cost everyone one more).
-__device__ __forceinline__ int weight_piece(int wave, int t) {
-    if (wave >= 4) return (wave - 4) + 4 * t;                 // 0 .. 11
-    return t == 0 ? 12 + wave : (t == 1 && wave < 2 ? 16 + wave : -1);
-}
-
 struct Item {
     int n, x0, y0, nb;
     bool valid;
