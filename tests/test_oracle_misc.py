@@ -17,6 +17,11 @@ def test_lab_known_values_and_round_trip():
     # sRGB red: L* 53.24, a* 80.09, b* 67.20 (standard D65 values)
     red = color_cpu.rgb2lab_single(torch.tensor([1.0, 0.0, 0.0]).view(3, 1, 1))
     np.testing.assert_allclose(red[:, 0, 0].numpy() * [100, 255, 255] - [0, 128, 128], [53.24, 80.09, 67.20], atol=0.02)
+    # the other published D65 / 2-degree values of the sRGB primaries and of mid grey (CIE 1976 L*a*b* of IEC 61966-2-1 sRGB)
+    for rgb1, want in (((0.0, 1.0, 0.0), (87.7347, -86.1827, 83.1793)), ((0.0, 0.0, 1.0), (32.2970, 79.1875, -107.8602)),
+                       ((0.5, 0.5, 0.5), (53.3890, 0.0, 0.0)), ((1.0, 1.0, 0.0), (97.1393, -21.5537, 94.4780))):
+        got = color_cpu.rgb2lab_single(torch.tensor(rgb1).view(3, 1, 1))[:, 0, 0].numpy() * [100, 255, 255] - [0, 128, 128]
+        np.testing.assert_allclose(got, want, atol=0.02)
     rng = np.random.default_rng(0)
     rgb = torch.from_numpy(rng.random((3, 16, 16), dtype=np.float32))
     back = color_cpu.lab2rgb_single(color_cpu.rgb2lab_single(rgb))
