@@ -146,6 +146,21 @@ template <bool INV> struct Dft<16, INV> {
 // composite radix R = R1 * R2 inside the registers (input index c + R1*r, output index q + R2*s):
 //   X[q + R2*s] = sum_c W_R1^(c*s) * W_R^(c*q) * (sum_r x[c + R1*r] * W_R2^(r*q))
 template <int R> struct Cis;       // exp(+2 pi i e / R) as {cos, sin}, e < R
+template <> struct Cis<6> {
+    static VFI_HD float2 at(int e) {
+        constexpr float h = 0.86602540378443864676f;
+        constexpr float t[6][2] = {{1.0f, 0.0f}, {0.5f, h}, {-0.5f, h}, {-1.0f, 0.0f}, {-0.5f, -h}, {0.5f, -h}};
+        return make_float2(t[e][0], t[e][1]);
+    }
+};
+template <> struct Cis<10> {
+    static VFI_HD float2 at(int e) {
+        constexpr float c1 = 0.80901699437494742410f, s1 = 0.58778525229247312917f;      // cos / sin (pi/5)
+        constexpr float c2 = 0.30901699437494742410f, s2 = 0.95105651629515357212f;      // cos / sin (2 pi/5)
+        constexpr float t[10][2] = {{1.0f, 0.0f}, {c1, s1}, {c2, s2}, {-c2, s2}, {-c1, s1}, {-1.0f, 0.0f}, {-c1, -s1}, {-c2, -s2}, {c2, -s2}, {c1, -s1}};
+        return make_float2(t[e][0], t[e][1]);
+    }
+};
 template <> struct Cis<9> {
     static VFI_HD float2 at(int e) {
         constexpr float t[9][2] = {{1.0f, 0.0f}, {0.76604444311897801345f, 0.64278760968653925190f}, {0.17364817766693041445f, 0.98480775301220802032f},
@@ -203,6 +218,8 @@ template <int R1, int R2, bool INV> struct DftComposite {
         }
     }
 };
+template <bool INV> struct Dft<6, INV> { static VFI_HD void run(float2 *v) { DftComposite<2, 3, INV>::run(v); } };
+template <bool INV> struct Dft<10, INV> { static VFI_HD void run(float2 *v) { DftComposite<2, 5, INV>::run(v); } };
 template <bool INV> struct Dft<9, INV> { static VFI_HD void run(float2 *v) { DftComposite<3, 3, INV>::run(v); } };
 template <bool INV> struct Dft<12, INV> { static VFI_HD void run(float2 *v) { DftComposite<3, 4, INV>::run(v); } };
 template <bool INV> struct Dft<15, INV> { static VFI_HD void run(float2 *v) { DftComposite<3, 5, INV>::run(v); } };

@@ -170,8 +170,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void fft_cols_kernel(cons
              });
 }
 
-template <typename K>
-void allow_lds(K kernel) {      // > 64 KiB of dynamic LDS needs the attribute, per device (idempotent)
+template <auto kernel>
+void allow_lds() {      // > 64 KiB of dynamic LDS needs the attribute, per KERNEL (not per signature) and device (idempotent)
     static bool done[vfi::kMaxDevices] = {};
     bool &d = done[vfi::current_device()];
     if (!d) {
@@ -183,8 +183,8 @@ void allow_lds(K kernel) {      // > 64 KiB of dynamic LDS needs the attribute, 
 
 template <int LOAD, int STORE>
 void launch_rows_dir(const RowArgs &a, bool inverse, dim3 grid, size_t lds, hipStream_t s) {
-    allow_lds(fft_rows_kernel<LOAD, STORE, true>);
-    allow_lds(fft_rows_kernel<LOAD, STORE, false>);
+    allow_lds<fft_rows_kernel<LOAD, STORE, true>>();
+    allow_lds<fft_rows_kernel<LOAD, STORE, false>>();
     if (inverse) hipLaunchKernelGGL((fft_rows_kernel<LOAD, STORE, true>), grid, dim3(kThreads), lds, s, a);
     else hipLaunchKernelGGL((fft_rows_kernel<LOAD, STORE, false>), grid, dim3(kThreads), lds, s, a);
 }
@@ -264,8 +264,8 @@ int launch_rows(const RowArgs &a, RowLoad load, RowStore store, bool inverse, hi
 int launch_cols(const ColArgs &a, bool inverse, hipStream_t s) {
     const dim3 grid((unsigned)vfi::ceil_div(a.cols, a.tile), (unsigned)a.planes);
     const size_t lds = col_lds_bytes(a.pl, a.tile);
-    allow_lds(fft_cols_kernel<true>);
-    allow_lds(fft_cols_kernel<false>);
+    allow_lds<fft_cols_kernel<true>>();
+    allow_lds<fft_cols_kernel<false>>();
     if (inverse) hipLaunchKernelGGL(fft_cols_kernel<true>, grid, dim3(kThreads), lds, s, a);
     else hipLaunchKernelGGL(fft_cols_kernel<false>, grid, dim3(kThreads), lds, s, a);
     return vfi::check_launch("fft column pass");

@@ -7,26 +7,30 @@
 // oracle/pyramid_cpu.py: level k works on the centred ceil(H/s^k) x ceil(W/s^k) window of the
 // spectrum, radial raised-cosine transition shifted by log2(s) per level, nbands oriented analytic bands.
 //
-// Roofline: HBM (target).  Every transform runs on the hand-written LDS FFT engine of vfi_fft.h (mixed-radix Stockham +
-// Bluestein; no FFT library is linked), and each pyramid level is two fused kernels per direction, so that no
-// intermediate of the reference's op-by-op chain (mask products, crops, shifts, deepcopy, band spectra, band
+// Roofline: HBM (target).  No FFT library is linked: the large levels run on the wave-private register FFT engine of
+// vfi_wfft.h (kernels in vfi_pyrw_kernels.h), every length that engine has no configuration for on the generic LDS
+// engine of vfi_fft.h (mixed-radix Stockham + Bluestein).  Each pyramid level is two fused kernels per direction, so that
+// no intermediate of the reference's op-by-op chain (mask products, crops, shifts, deepcopy, band spectra, band
 // coefficients, 2*L*N*4 atan2/abs launches) is materialised except ONE half-transformed array T:
-//   analysis  : column kernel : (column tile, image): reads the running low-pass spectrum, for each band multiplies by
-//                               the mask (i rotation applied, ifftshift by index arithmetic), inverse column FFT -> T;
-//                               also writes the cropped, low-pass filtered spectrum of the next level; level 0 also
-//                               expands the R2C half spectrum and emits the high-pass half spectrum for a C2R transform;
+//   analysis  : the low-pass chain of the build is a product of real masks, so every level reads the R2C half spectrum S
+//               of the image directly: level k, band b = IFFT2( i * window_k(S) * Q_k[b] ) with the table
+//               Q_k[b] = lo0 * prod_{j<k} lomask_j * himask_k * anglemask_b folded at plan time (double precision): the
+//               levels do not depend on each other and a level mask simply skips levels;
+//               column kernel : (column tile, image, band): window of S (Hermitian half expanded and ifftshift done by
+//                               index arithmetic) * Q, inverse column FFT -> T;
 //               row kernel    : rows of T -> inverse row FFT -> (phase, amplitude) written straight into the caller's
 //                               layout (per-image planes or PhaseNet's concat buffers), optional phase scale;
 //   synthesis : row kernel (A cos p, A sin p -> forward row FFT -> T), column kernel (forward column FFT, sum of
-//               rotated, masked band spectra + embedded low-pass of the coarser level).
-// Levels that a level mask excludes only pass the low-pass spectrum along (pyr_analysis_level_kernel /
-// pyr_combine_kernel without bands).
+//               rotated, masked band spectra + embedded low-pass of the coarser level); levels without bands only embed
+//               (pyr_combine_kernel).
 // All mask tables are precomputed once per plan in double precision, stored in the unshifted (FFT-native)
 // index order so every table read is coalesced with the spectrum access.
 #include "vfi_common.h"
 #include "vfi_fft.h"
+#include "vfi_pyramid_wave.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <new>
 #include <vector>
@@ -40,7 +44,7 @@ constexpr double kPi = 3.14159265358979323846;
 
 struct Level {
     int h, w;          // window size
-    float *P_a;        // [nb][h][w] analysis  : angle mask (one sided) * himask, unshifted order
+    float *P_a;        // [nb][h][w] analysis  : lo0 * prod_{j<k} lomask_j * himask_k * angle mask (one sided), unshifted order
     float *P_s;        // [nb][h][w] synthesis : angle mask (two sided) * himask
     float *lomask;     // [h2][w2]  low-pass applied to the NEXT level's window, unshifted order of that window
 };
@@ -53,6 +57,9 @@ struct vfi_pyr_plan {
     std::vector<Level> lev;      // nlev band levels
     int hl, wl;                  // low residual size
     float *lo0 = nullptr, *hi0 = nullptr;   // [H][W] unshifted
+    float *low_gain = nullptr;   // [hl][wl] lo0 * prod_j lomask_j on the low residual's window, unshifted
+    int tpitch_max = 0;          // row pitch of T the workspace is sized for (W rounded up to 16)
+    std::map<int, const float2 *> wave_tw_rows, wave_tw_cols;   // engine length -> stage twiddles (vfi_wfft.h)
     // workspace (complex64 unless noted)
     float2 *half0 = nullptr;     // N x H x (W/2+1)   R2C spectrum of the input / FFT of high on synthesis
     float2 *half_hi = nullptr;   // N x H x (W/2+1)   high-pass half spectrum (C2R input)
@@ -168,16 +175,29 @@ int build_tables(vfi_pyr_plan *p) {
     int rc;
     if ((rc = dev_upload(p, t, &p->lo0)) || (rc = dev_upload(p, t2, &p->hi0))) return rc;
 
+    // chain(s, k) = lo0 * prod_{j<k} lomask_j at the full-grid (shifted) position s: what the build's running low-pass
+    // spectrum has been multiplied by when level k reads it (`lodft = dft * lo0mask`, then `lodft * lomask` per level)
+    const double ls = std::log2(p->scale);
+    std::vector<std::vector<double>> xr_of(p->nlev + 1, p->xr0);      // xr_of[j] = xr0 - j * log2(scale)
+    for (int j = 1; j <= p->nlev; ++j)
+        for (auto &x : xr_of[j]) x -= j * ls;
+    auto chain = [&](size_t spos, int k) {
+        double c = interp(log_rad[spos], xr_of[0], yir);
+        for (int j = 1; j <= k; ++j) c *= interp(log_rad[spos], xr_of[j], yir);
+        return c;
+    };
     for (int k = 0; k < p->nlev; ++k) {
         Level &L = p->lev[k];
-        for (auto &x : xr) x -= std::log2(p->scale);
+        for (auto &x : xr) x -= ls;
         const int h = L.h, w = L.w, sy = H / 2 - h / 2, sx = W / 2 - w / 2;
         std::vector<float> pa((size_t)nb * h * w), ps((size_t)nb * h * w);
         std::vector<float> hm((size_t)h * w);
+        std::vector<double> ch((size_t)h * w);
         for (int u = 0; u < h; ++u)
             for (int v = 0; v < w; ++v) {
                 const size_t s = (size_t)(sy + shifted_of(u, h)) * W + (sx + shifted_of(v, w));
                 hm[(size_t)u * w + v] = (float)interp(log_rad[s], xr, yr);
+                ch[(size_t)u * w + v] = chain(s, k);
             }
         for (int b = 0; b < nb; ++b) {
             for (int i = 0; i < nl; ++i) xcb[i] = xc[i] + kPi * b / nb;
@@ -186,7 +206,7 @@ int build_tables(vfi_pyr_plan *p) {
                     const size_t s = (size_t)(sy + shifted_of(u, h)) * W + (sx + shifted_of(v, w));
                     const size_t o = ((size_t)b * h + u) * w + v;
                     // float32 tables of the oracle multiplied in fp32 there; here folded in double
-                    pa[o] = (float)((double)(float)interp(angle[s], xcb, ya) * (double)hm[(size_t)u * w + v]);
+                    pa[o] = (float)((double)(float)interp(angle[s], xcb, ya) * (double)hm[(size_t)u * w + v] * ch[(size_t)u * w + v]);
                     ps[o] = (float)((double)(float)interp(angle[s], xcb, ys) * (double)hm[(size_t)u * w + v]);
                 }
         }
@@ -201,103 +221,47 @@ int build_tables(vfi_pyr_plan *p) {
         if ((rc = dev_upload(p, pa, &L.P_a)) || (rc = dev_upload(p, ps, &L.P_s)) || (rc = dev_upload(p, lm, &L.lomask)))
             return rc;
     }
+    {   // low residual: real(ifft2(window(dft) * lo0 * prod_j lomask_j))
+        const int h2 = p->hl, w2 = p->wl, sy2 = H / 2 - h2 / 2, sx2 = W / 2 - w2 / 2;
+        std::vector<float> lg((size_t)h2 * w2);
+        for (int u = 0; u < h2; ++u)
+            for (int v = 0; v < w2; ++v)
+                lg[(size_t)u * w2 + v] = (float)chain((size_t)(sy2 + shifted_of(u, h2)) * W + (sx2 + shifted_of(v, w2)), p->nlev);
+        if ((rc = dev_upload(p, lg, &p->low_gain))) return rc;
+    }
     return VFI_OK;
 }
 
 // ---- device kernels ------------------------------------------------------------------------------------
-struct PlaneMap {          // where image d's band-0 plane goes, in planes of h*w elements from the level base
-    int idx[kMaxImages];
-    int band_stride;       // planes between consecutive bands of one image
-    int complex_coeff;     // 1: `phase` holds interleaved (re, im) coefficients, `amp` is unused
-};
+using vfi::pyrw::PlaneMap;      // where image d's band-0 plane goes (vfi_pyramid_wave.h)
 
 __device__ __forceinline__ int signed_freq(int u, int h) { return u <= h - h / 2 - 1 ? u : u - h; }
 
-// One thread per frequency bin (u, v) of level k's window (unshifted order), looping over the images.
-//   src  : FIRST ? R2C half spectrum N x H x (W/2+1)  :  running low-pass spectrum N x h x w
-//   band : N x NB x h x w  = i * src * P_a[b]                     (build: `lodft * anglemask * himask`, * (-i)^(nb-1))
-//   next : N x h2 x w2     = src * lomask   on the next window     (build: crop, `lomask * lodft`)
-//   FIRST: src = expand(half) * lo0 ; hi_half = half * hi0 / (H*W) for v <= W/2 (C2R input)
-template <bool FIRST, int NB>
-__global__ __launch_bounds__(256) void pyr_analysis_level_kernel(
-    const float2 *__restrict__ src, float2 *__restrict__ band, float2 *__restrict__ next,
-    float2 *__restrict__ hi_half, const float *__restrict__ P_a, const float *__restrict__ lomask,
-    const float *__restrict__ lo0, const float *__restrict__ hi0, int N, int h, int w, int h2, int w2,
-    int write_bands, float inv_hw) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    const int u = blockIdx.y;
-    if (v >= w) return;
-    const size_t hw = (size_t)h * w, o = (size_t)u * w + v;
-    float pa[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) pa[b] = write_bands ? P_a[(size_t)b * hw + o] : 0.0f;
-    const int fy = signed_freq(u, h), fx = signed_freq(v, w);
-    const bool inside = fy >= -(h2 / 2) && fy <= h2 - h2 / 2 - 1 && fx >= -(w2 / 2) && fx <= w2 - w2 / 2 - 1;
-    const int u2 = fy < 0 ? fy + h2 : fy, v2 = fx < 0 ? fx + w2 : fx;
-    const float lom = inside ? lomask[(size_t)u2 * w2 + v2] : 0.0f;
-    float l0 = 0.0f, h0 = 0.0f;
-    const int wh = w / 2 + 1;
-    if (FIRST) { l0 = lo0[o]; h0 = hi0[o]; }
+// high-pass half spectrum: hi_half = half * hi0 / (H W) (C2R input: `hi0dft = dft * hi0mask`, real(ifft2) of it)
+__global__ __launch_bounds__(256) void pyr_high_kernel(const float2 *__restrict__ half, float2 *__restrict__ hi_half,
+                                                       const float *__restrict__ hi0, int N, int H, int W, float inv_hw) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y, wh = W / 2 + 1;
+    if (v >= wh) return;
+    const float g = hi0[(size_t)u * W + v] * inv_hw;
     for (int n = 0; n < N; ++n) {
-        float2 z;
-        if (FIRST) {
-            if (v < wh) {
-                z = src[((size_t)n * h + u) * wh + v];
-                hi_half[((size_t)n * h + u) * wh + v] = make_float2(z.x * h0 * inv_hw, z.y * h0 * inv_hw);
-            } else {
-                const float2 c = src[((size_t)n * h + (u ? h - u : 0)) * wh + (w - v)];
-                z = make_float2(c.x, -c.y);
-            }
-            z = make_float2(z.x * l0, z.y * l0);
-        } else {
-            z = src[(size_t)n * hw + o];
-        }
-        if (write_bands) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b)  // * i : (re, im) -> (-im, re)
-                band[((size_t)n * NB + b) * hw + o] = make_float2(-(z.y * pa[b]), z.x * pa[b]);
-        }
-        if (inside) next[((size_t)n * h2 + u2) * w2 + v2] = make_float2(z.x * lom, z.y * lom);
+        const float2 z = half[((size_t)n * H + u) * wh + v];
+        hi_half[((size_t)n * H + u) * wh + v] = make_float2(z.x * g, z.y * g);
     }
 }
 
-// complex band coefficient (after the un-normalised inverse FFT) -> phase, amplitude in the caller's layout
-// (coeff_to_values: src/train/pyramid.py:63-69)
-template <int NB>
-__global__ __launch_bounds__(256) void pyr_polar_kernel(const float2 *__restrict__ band, float *__restrict__ phase,
-                                                        float *__restrict__ amp, PlaneMap pm, int N, int hw,
-                                                        float inv_hw, float phase_scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nb_idx = blockIdx.y;  // n * NB + b
-    if (i >= hw) return;
-    const int n = nb_idx / NB, b = nb_idx % NB;
-    const float2 z = band[(size_t)nb_idx * hw + i];
-    const float re = z.x * inv_hw, im = z.y * inv_hw;
-    const size_t o = (size_t)(pm.idx[n] + b * pm.band_stride) * hw + i;
-    if (pm.complex_coeff) {
-        reinterpret_cast<float2 *>(phase)[o] = make_float2(re, im);
-    } else {
-        phase[o] = atan2f(im, re) * phase_scale;
-        amp[o] = sqrtf(re * re + im * im);
-    }
-}
-
-// (phase, amplitude) -> complex coefficient (values_to_coeff: src/train/pyramid.py:99-107)
-template <int NB>
-__global__ __launch_bounds__(256) void pyr_to_complex_kernel(const float *__restrict__ phase, const float *__restrict__ amp,
-                                                             float2 *__restrict__ band, PlaneMap pm, int N, int hw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nb_idx = blockIdx.y;
-    if (i >= hw) return;
-    const int n = nb_idx / NB, b = nb_idx % NB;
-    const size_t o = (size_t)(pm.idx[n] + b * pm.band_stride) * hw + i;
-    if (pm.complex_coeff) {
-        band[(size_t)nb_idx * hw + i] = reinterpret_cast<const float2 *>(phase)[o];
-    } else {
-        float s, c;
-        sincosf(phase[o], &s, &c);
-        const float a = amp[o];
-        band[(size_t)nb_idx * hw + i] = make_float2(c * a, s * a);
+// low residual spectrum: the (hl x wl) window of the expanded half spectrum * low_gain (unshifted order)
+__global__ __launch_bounds__(256) void pyr_low_kernel(const float2 *__restrict__ half, float2 *__restrict__ low,
+                                                      const float *__restrict__ gain, int N, int H, int W, int hl, int wl) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= hl * wl) return;
+    const int u = e / wl, v = e - u * wl, wh = W / 2 + 1;
+    const int fy = signed_freq(u, hl), fx = signed_freq(v, wl);
+    const int U = fx < 0 ? (fy > 0 ? H - fy : -fy) : (fy < 0 ? fy + H : fy), V = fx < 0 ? -fx : fx;
+    const float g = gain[e];
+    for (int n = 0; n < N; ++n) {
+        float2 z = half[((size_t)n * H + U) * wh + V];
+        if (fx < 0) z.y = -z.y;
+        low[(size_t)n * hl * wl + e] = make_float2(z.x * g, z.y * g);
     }
 }
 
@@ -409,14 +373,11 @@ using vfi::fft::mul24;
 
 struct LevelColsArgs {
     Plan1D ph;                    // column transform (length h)
-    const float2 *src;            // FIRST: R2C half spectrum N x H x (W/2+1); else running low-pass N x h x w
+    const float2 *src;            // R2C half spectrum of the images, N x H x (W/2+1)
     float2 *T;                    // N x NB x h x w
-    float2 *next;                 // N x h2 x w2 (may be null when nothing is below)
-    float2 *hi_half;              // FIRST only
-    const float *P, *lomask, *lo0, *hi0;
-    int h, w, h2, w2, tile;
+    const float *P;               // Q_k: [NB][h][w]
+    int h, w, H, W, tile;
     int bands_per_pass;           // 1, 2 or 4: how many bands go through ONE transform call as extra lines (small levels)
-    float inv_hw;                 // FIRST: 1 / (H W) folded into the high-pass half spectrum
 };
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (own L2).  A column tile is only tile*8 bytes wide, so the tiles
@@ -426,83 +387,33 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles) {
     return (b & 7) * per + (b >> 3);
 }
 
+// Generic-engine form of the analysis column pass (lengths the wave engine has no configuration for; the same
+// arithmetic as vfi_pyrw_kernels.h: ana_cols_kernel).
 // BLU: the transform length goes through Bluestein (chirp factors in the fill / drain).  A compile-time constant: with a
 // run-time flag every fill / drain carries conditional chirp loads, and the compiler then waits for ALL outstanding
 // memory operations (vmcnt(0): loads and stores share the counter) in front of every element -- also on the smooth
 // levels, the large ones, that never load a chirp factor.
-template <bool FIRST, int NB, bool BLU>
+template <int NB, bool BLU>
 __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_level_cols_kernel(const LevelColsArgs a) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
-    const int h = a.h, w = a.w, m = a.ph.m, tid = threadIdx.x, C = a.tile, n = blockIdx.y;
+    const int h = a.h, w = a.w, H = a.H, m = a.ph.m, tid = threadIdx.x, C = a.tile, n = blockIdx.y;
     const int ntiles = (w + C - 1) / C;
     const int tile = tile_of_block(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
     const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);
     const int v0 = tile * C, lines = w - v0 < C ? w - v0 : C;
-    const int shift = __ffs(C) - 1, total = h * C, wh = w / 2 + 1;
+    const int shift = __ffs(C) - 1, wh = a.W / 2 + 1;
     constexpr bool blu = BLU;
     const size_t hw = (size_t)h * w;
-    const float2 *srcn = a.src + (FIRST ? (size_t)n * h * wh : (size_t)n * hw);      // (32-bit offsets inside a plane)
-    auto load_z = [&](int u, int v) -> float2 {          // this level's low-pass spectrum at (u, v)
-        if (FIRST) {
-            float2 z;
-            if (v < wh) z = srcn[mul24(u, wh) + v];
-            else { z = srcn[mul24(u ? h - u : 0, wh) + (w - v)]; z.y = -z.y; }
-            const float l0 = a.lo0[mul24(u, w) + v];
-            return make_float2(z.x * l0, z.y * l0);
-        }
-        return srcn[mul24(u, w) + v];
+    const float2 *srcn = a.src + (size_t)n * H * wh;                      // (32-bit offsets inside a plane)
+    auto load_z = [&](int u, int v) -> float2 {          // the level's window of the expanded half spectrum at (u, v)
+        const int fy = signed_freq(u, h), fx = signed_freq(v, w);
+        if (fx >= 0) return srcn[mul24(fy < 0 ? fy + H : fy, wh) + fx];
+        float2 z = srcn[mul24(fy > 0 ? H - fy : -fy, wh) - fx];
+        z.y = -z.y;
+        return z;
     };
-    // -- the next level's low-pass spectrum (crop + lomask) and, at level 0, the high-pass half spectrum ------------
-    if (a.next) {
-        const int h2 = a.h2, w2 = a.w2;
-        float2 *nextn = a.next + (size_t)n * h2 * w2;
-        auto window = [&](int e, int &o2) -> bool {       // is element e inside the next level's window? -> its offset there
-            const int u = e >> shift, cc = e & (C - 1), v = v0 + cc;
-            if (cc >= lines) return false;
-            const int fy = signed_freq(u, h), fx = signed_freq(v, w);
-            if (!(fy >= -(h2 / 2) && fy <= h2 - h2 / 2 - 1 && fx >= -(w2 / 2) && fx <= w2 - w2 / 2 - 1)) return false;
-            o2 = mul24(fy < 0 ? fy + h2 : fy, w2) + (fx < 0 ? fx + w2 : fx);
-            return true;
-        };
-        for_slots(total,
-                  [&](int e) {
-                      Slot s;
-                      int o2 = 0;
-                      s.z = make_float2(0.0f, 0.0f);
-                      s.s = 0.0f;
-                      if (window(e, o2)) {
-                          s.z = load_z(e >> shift, v0 + (e & (C - 1)));
-                          s.s = a.lomask[o2];
-                      }
-                      return s;
-                  },
-                  [&](int e, const Slot &s) {
-                      int o2 = 0;
-                      if (window(e, o2)) nextn[o2] = make_float2(s.z.x * s.s, s.z.y * s.s);
-                  });
-    }
-    if (FIRST && a.hi_half) {
-        float2 *hin = a.hi_half + (size_t)n * h * wh;
-        for_slots(total,
-                  [&](int e) {
-                      const int u = e >> shift, cc = e & (C - 1), v = v0 + cc;
-                      Slot s;
-                      s.z = make_float2(0.0f, 0.0f);
-                      s.s = 0.0f;
-                      if (cc < lines && v < wh) {
-                          s.z = srcn[mul24(u, wh) + v];
-                          s.s = a.hi0[mul24(u, w) + v] * a.inv_hw;
-                      }
-                      return s;
-                  },
-                  [&](int e, const Slot &s) {
-                      const int u = e >> shift, cc = e & (C - 1), v = v0 + cc;
-                      if (cc < lines && v < wh) hin[mul24(u, wh) + v] = make_float2(s.z.x * s.s, s.z.y * s.s);
-                  });
-    }
-    if (!a.T) return;
     float2 *twl = buf + (size_t)a.bands_per_pass * C * pitch;
     load_twiddles(twl, a.ph);
     // this thread's column of the tile (for_tile): validity, a safe column to read, offset of (row u0, that column)
@@ -513,22 +424,16 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_level_cols_kerne
 #pragma unroll 1
     for (int b0 = 0; b0 < NB; b0 += BP) {
       for (int bb = 0; bb < BP; ++bb) {
-        // fill: conj(i * z * P_a[b]) (* chirp): the inverse transform runs as a forward one on conjugated data.  The tile
+        // fill: conj(i * z * Q[b]) (* chirp): the inverse transform runs as a forward one on conjugated data.  The tile
         // of z is re-read per band (L2) rather than kept in 70 registers across the stage calls.
         const int b = b0 + bb;
         float2 *bufb = buf + mul24(bb * C, pitch);
         const float *Pb = a.P + (size_t)b * hw;
         for_tile(h, shift, pitch,
-                 [&](int u, int uq, int) {
+                 [&](int u, int, int) {
                      Slot s;
-                     if (FIRST) {
-                         s.z = load_z(u, vt);
-                         s.s = Pb[mul24(u, w) + vt];
-                     } else {                              // per-thread base + uniform row offset
-                         const int o = tb + mul24(uq, w);
-                         s.z = srcn[o];
-                         s.s = Pb[o];
-                     }
+                     s.z = load_z(u, vt);
+                     s.s = Pb[mul24(u, w) + vt];
                      if (blu) s.c = a.ph.chirp[u];
                      return s;
                  },
@@ -836,8 +741,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_combine_cols_ker
     }
 }
 
-template <typename K>
-void allow_big_lds(K kernel) {      // > 64 KiB of dynamic LDS needs the attribute, per device (idempotent)
+template <auto kernel>
+void allow_big_lds() {      // > 64 KiB of dynamic LDS needs the attribute, per KERNEL (not per signature) and device (idempotent)
     static bool done[vfi::kMaxDevices] = {};
     bool &d = done[vfi::current_device()];
     if (!d) {
@@ -882,6 +787,36 @@ int get_fft(vfi_pyr_plan *p, int n, vfi::fft::Plan1D *out) {
     *out = it->second;
     return VFI_OK;
 }
+
+// ---- wave engine (vfi_wfft.h) selection: engine length of a pass or 0, and its stage twiddles (built once per plan) ----
+int wave_twiddles(vfi_pyr_plan *p, bool cols, int M, const float2 **out) {
+    auto &cache = cols ? p->wave_tw_cols : p->wave_tw_rows;
+    auto it = cache.find(M);
+    if (it == cache.end()) {
+        std::vector<float2> tw(4096);
+        const int cnt = cols ? vfi::pyrw::cols_twiddles(M, tw.data(), (int)tw.size()) : vfi::pyrw::rows_twiddles(M, tw.data(), (int)tw.size());
+        if (cnt < 0) return vfi::fail(VFI_ERR_UNSUPPORTED, "pyramid: no wave-engine twiddles for length %d", M);
+        tw.resize(cnt > 0 ? cnt : 1);
+        float2 *dev = nullptr;
+        const int rc = dev_upload(p, tw, &dev);
+        if (rc) return rc;
+        it = cache.emplace(M, dev).first;
+    }
+    *out = it->second;
+    return VFI_OK;
+}
+// tables of a pass on the wave engine; tb->M == 0 when the engine has no configuration for this length
+int wave_tables(vfi_pyr_plan *p, bool cols, const vfi::fft::Plan1D &pl, vfi::pyrw::Tables *tb) {
+    static const bool off = [] { const char *e = getenv("VFI_PYR_WAVE"); return e && e[0] == '0'; }();      // (A/B switch)
+    *tb = vfi::pyrw::Tables{};
+    const int M = off ? 0 : (cols ? vfi::pyrw::cols_engine_length(pl.n, pl.bluestein ? pl.m : 0) : vfi::pyrw::rows_engine_length(pl.n, pl.bluestein ? pl.m : 0));
+    if (!M) return VFI_OK;
+    const int rc = wave_twiddles(p, cols, M, &tb->tw);
+    if (rc) return rc;
+    tb->chirp = pl.chirp; tb->bfilt = pl.bfilt; tb->M = M; tb->n = pl.n; tb->bluestein = pl.bluestein;
+    return VFI_OK;
+}
+inline int round_up16(int x) { return (x + 15) & ~15; }
 
 // in-place complex 2-D transform of `planes` dense h x w arrays (un-normalised)
 int fft2d_c2c(vfi_pyr_plan *p, float2 *data, int planes, int h, int w, bool inverse, hipStream_t s) {
@@ -959,11 +894,15 @@ extern "C" int vfi_pyr_plan_create(int H, int W, int height, int nbands, double 
     {   // FFT tables of every length the plan can meet (so that no later call allocates)
         vfi::fft::Plan1D tmp;
         for (int k = 0; k <= p->nlev && !rc; ++k) {
+            vfi::pyrw::Tables tb;
             rc = get_fft(p, k < p->nlev ? p->lev[k].h : p->hl, &tmp);
+            if (!rc && k < p->nlev) rc = wave_tables(p, true, tmp, &tb);
             if (!rc) rc = get_fft(p, k < p->nlev ? p->lev[k].w : p->wl, &tmp);
+            if (!rc && k < p->nlev) rc = wave_tables(p, false, tmp, &tb);
         }
     }
-    const size_t N = max_images, HW = (size_t)H * W, half = (size_t)H * (W / 2 + 1);
+    p->tpitch_max = round_up16(W);
+    const size_t N = max_images, HW = (size_t)H * p->tpitch_max, half = (size_t)H * (W / 2 + 1);
     if (!rc) rc = dev_alloc(p, (void **)&p->half0, N * half * sizeof(float2));
     if (!rc) rc = dev_alloc(p, (void **)&p->half_hi, N * half * sizeof(float2));
     if (!rc) rc = dev_alloc(p, (void **)&p->bands, N * nbands * HW * sizeof(float2));
@@ -1075,66 +1014,70 @@ static int pyr_analyze_impl(vfi_pyr_plan *p, const float *img, int N, float *hig
     if (amp_max && hipMemsetAsync(p->amp_bits, 0, sizeof(unsigned) * p->nlev * groups, s) != hipSuccess)
         return vfi::fail(VFI_ERR_LAUNCH, "vfi_pyr_analyze_max: memset");
     if ((rc = fft2d_r2c(p, img, p->half0, N, s))) return rc;
-    const float2 *src = p->half0;
     for (int k = 0; k < p->nlev; ++k) {
         const Level &L = p->lev[k];
-        const int h2 = k + 1 < p->nlev ? p->lev[k + 1].h : p->hl, w2 = k + 1 < p->nlev ? p->lev[k + 1].w : p->wl;
-        float2 *next = p->lod[k & 1];
-        const int wb = (level_mask >> k) & 1ull ? 1 : 0;
-        if (wb) VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
-                            "vfi_pyr_analyze: null output for level %d", k);
-        const bool need_next = (level_mask >> (k + 1)) != 0 || low != nullptr;     // anything below this level?
-        if (!wb) {      // level not wanted: only pass the low-pass spectrum down (and emit the high-pass half spectrum)
-            if (!need_next && !(k == 0 && high)) { src = next; continue; }
-            dim3 grid(ceil_div(L.w, 256), L.h);
-            if (k == 0)
-                hipLaunchKernelGGL((pyr_analysis_level_kernel<true, 4>), grid, dim3(256), 0, s, src, p->bands, next, p->half_hi,
-                                   L.P_a, L.lomask, p->lo0, p->hi0, N, L.h, L.w, h2, w2, 0, 1.0f / ((float)H * (float)W));
-            else
-                hipLaunchKernelGGL((pyr_analysis_level_kernel<false, 4>), grid, dim3(256), 0, s, src, p->bands, next, nullptr,
-                                   L.P_a, L.lomask, nullptr, nullptr, N, L.h, L.w, h2, w2, 0, 0.0f);
-            src = next;
-            continue;
-        }
+        if (!((level_mask >> k) & 1ull)) continue;      // (the levels read the half spectrum directly: nothing to pass along)
+        VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
+                    "vfi_pyr_analyze: null output for level %d", k);
         using namespace vfi::fft;
         Plan1D ph, pw;
-        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw))) return rc;
-        int tile, bpp;
-        level_tiling(ph, L.w, &tile, &bpp);
-        LevelColsArgs ca{ph, src, p->bands, need_next ? next : nullptr, k == 0 && high ? p->half_hi : nullptr, L.P_a, L.lomask,
-                         p->lo0, p->hi0, L.h, L.w, h2, w2, tile, bpp, 1.0f / ((float)H * (float)W)};
-        const dim3 cgrid(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N);
-        const size_t clds = level_lds_bytes(ph, tile, bpp);
-#define VFI_LAUNCH_COLS(FIRST, BLU)                              \
-    allow_big_lds(pyr_level_cols_kernel<FIRST, 4, BLU>);         \
-    hipLaunchKernelGGL((pyr_level_cols_kernel<FIRST, 4, BLU>), cgrid, dim3(kThreads), clds, s, ca)
-        if (k == 0) { if (ph.bluestein) { VFI_LAUNCH_COLS(true, true); } else { VFI_LAUNCH_COLS(true, false); } }
-        else { if (ph.bluestein) { VFI_LAUNCH_COLS(false, true); } else { VFI_LAUNCH_COLS(false, false); } }
-#undef VFI_LAUNCH_COLS
-        const long long rows = (long long)N * nb * L.h;
-        int lines = rows_per_group(pw, rows);
-        if (lines > 256) lines = 256;
-        RowsPolarArgs ra{pw, p->bands, phase[k], amp ? amp[k] : nullptr, make_map(plane_index, k, N, nb, flags), rows, L.h, lines,
-                         1.0f / ((float)L.h * (float)L.w), phase_scale, amp_max ? p->amp_bits + (size_t)k * groups : nullptr, groups};
-        if (pw.bluestein) {
-            allow_big_lds(pyr_rows_polar_kernel<4, true>);
-            hipLaunchKernelGGL((pyr_rows_polar_kernel<4, true>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
-                               row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        vfi::pyrw::Tables tbh, tbw;
+        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw)) || (rc = wave_tables(p, true, ph, &tbh)) ||
+            (rc = wave_tables(p, false, pw, &tbw)))
+            return rc;
+        const int tpitch = tbh.M && tbw.M ? round_up16(L.w) : L.w;      // (the generic kernels address T densely)
+        const PlaneMap pm = make_map(plane_index, k, N, nb, flags);
+        unsigned *amax = amp_max ? p->amp_bits + (size_t)k * groups : nullptr;
+        if (tbh.M) {
+            vfi::pyrw::AnaColsArgs ca{tbh, p->half0, W / 2 + 1, H, L.P_a, p->bands, tpitch, N, L.h, L.w};
+            if ((rc = vfi::pyrw::launch_ana_cols(ca, s))) return rc;
         } else {
-            allow_big_lds(pyr_rows_polar_kernel<4, false>);
-            hipLaunchKernelGGL((pyr_rows_polar_kernel<4, false>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
-                               row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+            int tile, bpp;
+            level_tiling(ph, L.w, &tile, &bpp);
+            LevelColsArgs ca{ph, p->half0, p->bands, L.P_a, L.h, L.w, H, W, tile, bpp};
+            const dim3 cgrid(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N);
+            const size_t clds = level_lds_bytes(ph, tile, bpp);
+            if (ph.bluestein) {
+                allow_big_lds<pyr_level_cols_kernel<4, true>>();
+                hipLaunchKernelGGL((pyr_level_cols_kernel<4, true>), cgrid, dim3(kThreads), clds, s, ca);
+            } else {
+                allow_big_lds<pyr_level_cols_kernel<4, false>>();
+                hipLaunchKernelGGL((pyr_level_cols_kernel<4, false>), cgrid, dim3(kThreads), clds, s, ca);
+            }
         }
-        src = next;
+        if (tbw.M) {
+            vfi::pyrw::RowsArgs ra{tbw, p->bands, tpitch, phase[k], amp ? amp[k] : nullptr, pm, N * nb, L.h, L.w,
+                                   1.0f / ((float)L.h * (float)L.w), phase_scale, amax, groups};
+            if ((rc = vfi::pyrw::launch_rows_polar(ra, s))) return rc;
+        } else {
+            const long long rows = (long long)N * nb * L.h;
+            int lines = rows_per_group(pw, rows);
+            if (lines > 256) lines = 256;
+            RowsPolarArgs ra{pw, p->bands, phase[k], amp ? amp[k] : nullptr, pm, rows, L.h, lines,
+                             1.0f / ((float)L.h * (float)L.w), phase_scale, amax, groups};
+            if (pw.bluestein) {
+                allow_big_lds<pyr_rows_polar_kernel<4, true>>();
+                hipLaunchKernelGGL((pyr_rows_polar_kernel<4, true>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                                   row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+            } else {
+                allow_big_lds<pyr_rows_polar_kernel<4, false>>();
+                hipLaunchKernelGGL((pyr_rows_polar_kernel<4, false>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                                   row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+            }
+        }
     }
-    if (low) {  // low residual: real(ifft2(lodft))
-        float2 *buf = const_cast<float2 *>(src);
+    if (low) {  // low residual: real(ifft2(window(dft) * low_gain))
+        float2 *buf = p->lod[0];
+        const int tot1 = p->hl * p->wl;
+        hipLaunchKernelGGL(pyr_low_kernel, dim3(ceil_div(tot1, 256)), dim3(256), 0, s, p->half0, buf, p->low_gain, N, H, W, p->hl, p->wl);
         if ((rc = fft2d_c2c(p, buf, N, p->hl, p->wl, true, s))) return rc;
-        const long long tot = (long long)N * p->hl * p->wl;
+        const long long tot = (long long)N * tot1;
         hipLaunchKernelGGL(complex_real_kernel, dim3(blocks_1d(tot)), dim3(256), 0, s, buf, low, tot,
                            1.0f / ((float)p->hl * (float)p->wl));
     }
     if (high) {  // high residual: C2R of half * hi0 / (H W)
+        hipLaunchKernelGGL(pyr_high_kernel, dim3(ceil_div(W / 2 + 1, 256), H), dim3(256), 0, s, p->half0, p->half_hi, p->hi0, N, H, W,
+                           1.0f / ((float)H * (float)W));
         if ((rc = fft2d_c2r(p, p->half_hi, high, N, s))) return rc;
     }
     if (amp_max) {
@@ -1190,32 +1133,48 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
                     "vfi_pyr_synthesize: null input for level %d", k);
         using namespace vfi::fft;
         Plan1D ph, pw;
-        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw))) return rc;
-        const long long rows = (long long)N * nb * L.h;
-        int lines = rows_per_group(pw, rows);
-        if (lines > 256) lines = 256;
-        RowsPolarArgs ra{pw, p->bands, const_cast<float *>(phase[k]), amp ? const_cast<float *>(amp[k]) : nullptr,
-                         make_map(plane_index, k, N, nb, flags), rows, L.h, lines, 1.0f, 1.0f, nullptr, 1};
-        if (pw.bluestein) {
-            allow_big_lds(pyr_rows_from_polar_kernel<4, true>);
-            hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4, true>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
-                               row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+        vfi::pyrw::Tables tbh, tbw;
+        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw)) || (rc = wave_tables(p, true, ph, &tbh)) ||
+            (rc = wave_tables(p, false, pw, &tbw)))
+            return rc;
+        const int tpitch = tbh.M && tbw.M ? round_up16(L.w) : L.w;
+        const PlaneMap pm = make_map(plane_index, k, N, nb, flags);
+        if (tbw.M) {
+            vfi::pyrw::RowsArgs ra{tbw, p->bands, tpitch, const_cast<float *>(phase[k]), amp ? const_cast<float *>(amp[k]) : nullptr, pm,
+                                   N * nb, L.h, L.w, 1.0f, 1.0f, nullptr, 1};
+            if ((rc = vfi::pyrw::launch_rows_from_polar(ra, s))) return rc;
         } else {
-            allow_big_lds(pyr_rows_from_polar_kernel<4, false>);
-            hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4, false>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
-                               row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+            const long long rows = (long long)N * nb * L.h;
+            int lines = rows_per_group(pw, rows);
+            if (lines > 256) lines = 256;
+            RowsPolarArgs ra{pw, p->bands, const_cast<float *>(phase[k]), amp ? const_cast<float *>(amp[k]) : nullptr, pm, rows, L.h,
+                             lines, 1.0f, 1.0f, nullptr, 1};
+            if (pw.bluestein) {
+                allow_big_lds<pyr_rows_from_polar_kernel<4, true>>();
+                hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4, true>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                                   row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+            } else {
+                allow_big_lds<pyr_rows_from_polar_kernel<4, false>>();
+                hipLaunchKernelGGL((pyr_rows_from_polar_kernel<4, false>), dim3((unsigned)((rows + lines - 1) / lines)), dim3(kThreads),
+                                   row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)), s, ra);
+            }
         }
-        int tile, bpp;
-        level_tiling(ph, L.w, &tile, &bpp);
-        CombineColsArgs ca{ph, p->bands, res, cur, L.P_s, L.lomask, L.h, L.w, h2, w2, tile, bpp};
-        if (ph.bluestein) {
-            allow_big_lds(pyr_combine_cols_kernel<4, true>);
-            hipLaunchKernelGGL((pyr_combine_cols_kernel<4, true>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
-                               level_lds_bytes(ph, tile, bpp), s, ca);
+        if (tbh.M) {
+            vfi::pyrw::SynColsArgs ca{tbh, p->bands, tpitch, L.P_s, res, L.lomask, cur, N, L.h, L.w, h2, w2};
+            if ((rc = vfi::pyrw::launch_syn_cols(ca, s))) return rc;
         } else {
-            allow_big_lds(pyr_combine_cols_kernel<4, false>);
-            hipLaunchKernelGGL((pyr_combine_cols_kernel<4, false>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
-                               level_lds_bytes(ph, tile, bpp), s, ca);
+            int tile, bpp;
+            level_tiling(ph, L.w, &tile, &bpp);
+            CombineColsArgs ca{ph, p->bands, res, cur, L.P_s, L.lomask, L.h, L.w, h2, w2, tile, bpp};
+            if (ph.bluestein) {
+                allow_big_lds<pyr_combine_cols_kernel<4, true>>();
+                hipLaunchKernelGGL((pyr_combine_cols_kernel<4, true>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
+                                   level_lds_bytes(ph, tile, bpp), s, ca);
+            } else {
+                allow_big_lds<pyr_combine_cols_kernel<4, false>>();
+                hipLaunchKernelGGL((pyr_combine_cols_kernel<4, false>), dim3(8 * ceil_div(ceil_div(L.w, ca.tile), 8), N), dim3(kThreads),
+                                   level_lds_bytes(ph, tile, bpp), s, ca);
+            }
         }
         res = cur;
     }

@@ -13,8 +13,8 @@ class Model(nn.Module):
         super().__init__()
         self.model = import_module(args.model.lower()).make_model(args)
 
-    def forward(self, frame0, frame1):
-        return self.model(frame0, frame1)
+    def forward(self, frame0, frame1, **kwargs):
+        return self.model(frame0, frame1, **kwargs)     # (kwargs: the fusion variant's per-call `return_sides`)
 
     def load(self, state_dict):
         self.model.load_state_dict(state_dict)

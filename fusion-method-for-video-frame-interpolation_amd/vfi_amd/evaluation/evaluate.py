@@ -12,8 +12,9 @@ Same flags and flow as the reference (`parser` :28-73, `eval` :219-278):
 Differences in execution, not results: predictions and targets are decoded to the GPU and scored there
 (vfi_amd.evaluation.evaluate_image: PSNR/SSIM/ad-hoc measures as deterministic device reductions; LPIPS column NaN --
 needs pretrained VGG weights that ship neither with the reference nor with this image); with torch.distributed
-initialised (one process per GPU) the test sets are dealt round-robin to the ranks -- no collective: every rank writes
-its own result_<set>.npy and the caches make a second pass on any rank complete.  The matplotlib figures of
+initialised (one process per GPU, rank r on GPU LOCAL_RANK) the test sets are dealt round-robin to the ranks -- no
+collective: every rank writes its own result_<set>.npy and the caches make a second pass on any rank complete; an
+explicit --base_dir is required then, and a set without predictions raises instead of caching an empty array.  The matplotlib figures of
 visualizations.py (:254-258,299-300) are out of scope; `eval` returns the per-set arrays and prints NaN-aware means.
 """
 import argparse
@@ -133,9 +134,27 @@ def build_models(args):
     return adacof_model, fusion_net
 
 
+def _wait_for(path, timeout_s=24 * 3600.0, poll_s=2.0):
+    """File-based hand-off between ranks (no collective on the data path): blocks until `path` exists."""
+    import time
+    t0 = time.monotonic()
+    while not os.path.exists(path):
+        if time.monotonic() - t0 > timeout_s:
+            raise TimeoutError("evaluate: waited {:.0f} s for {}".format(timeout_s, path))
+        time.sleep(poll_s)
+
+
 def eval(args, rank=None, world=None):           # noqa: A001  (the reference's name)
+    local_rank = None
     if rank is None:
-        rank, _, world = shard.env_world()
+        rank, local_rank, world = shard.env_world()
+    if world > 1:
+        # one process per GPU: rank r works on GPU LOCAL_RANK (the reference is single-process and uses --gpu_id);
+        # the default --base_dir embeds this process's start time, so the ranks would not agree on it
+        if local_rank is not None:
+            args.gpu_id = local_rank % max(torch.cuda.device_count(), 1)
+        if args.base_dir == parser.get_default("base_dir"):
+            raise SystemExit("evaluate: --base_dir must be given explicitly when WORLD_SIZE > 1 (the default is per process)")
     torch.cuda.set_device(args.gpu_id)
     random.seed(args.seed)
     root = getattr(args, "testset_root", "Testset")
@@ -143,8 +162,13 @@ def eval(args, rank=None, world=None):           # noqa: A001  (the reference's 
     os.makedirs(img_output_dir, exist_ok=True)
     adacof_model, fusion_net = build_models(args)
     if getattr(args, "vimeo_testset", False):
+        # the triplet list is one flat file: rank 0 interpolates it, the others wait for its marker before they score
+        marker = os.path.join(img_output_dir, ".vimeo_interpolated")
         if rank == 0:
             interpolate.interpolate_dataset(args, adacof_model, fusion_net)
+            open(marker, "w").close()
+        else:
+            _wait_for(marker)
         args.test_sets = [os.path.basename(x) for x in sorted(glob.glob(os.path.join(root, "vimeo_interp_test", "target", "*")))]
     mine = [t for i, t in enumerate(args.test_sets) if i % world == rank]
     if not getattr(args, "vimeo_testset", False):
@@ -156,7 +180,12 @@ def eval(args, rank=None, world=None):           # noqa: A001  (the reference's 
         if os.path.exists(result_path):
             result_np = np.load(result_path)
         else:
-            result_np = np.array(evaluate_dataset(args, testset))
+            rows = evaluate_dataset(args, testset)
+            if not rows:
+                # the reference raises IndexError here (evaluate.py:112-130 index an empty list); an empty array must never
+                # become a cache entry that later runs would take for a result
+                raise IndexError("evaluate: no interpolated images found for test set '{}' under {}".format(testset, img_output_dir))
+            result_np = np.array(rows)
             np.save(result_path, result_np)
         results_np[testset] = result_np
         if result_np.size:

@@ -61,8 +61,11 @@ def interpolate_dataset(args, adacof_model, fusion_net, dataset_path="", max_num
     return done
 
 
-def interpolate_vimeo_testset(args, adacof_model, fusion_net, root=os.path.join("Testset", "vimeo_interp_test")):
-    """interpolate.py:161-209: triplets listed in tri_testlist.txt, im1/im3 -> im2."""
+def interpolate_vimeo_testset(args, adacof_model, fusion_net, root=None):
+    """interpolate.py:161-209: triplets listed in tri_testlist.txt, im1/im3 -> im2 (under <testset_root>/vimeo_interp_test,
+    the same root the scoring side reads)."""
+    if root is None:
+        root = os.path.join(getattr(args, "testset_root", "Testset"), "vimeo_interp_test")
     with open(os.path.join(root, "tri_testlist.txt")) as f:
         triplets = [x.strip() for x in f.readlines() if x.strip()]
     done = 0

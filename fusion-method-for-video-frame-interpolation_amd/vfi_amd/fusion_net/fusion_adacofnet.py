@@ -150,19 +150,18 @@ class AdaCoFNet(torch.nn.Module):
             raise NotImplementedError("vfi_amd implements the inference path only (eval mode)")
         return super().train(False)
 
-    # The reference returns both sampled sides (tensorAdaCoF1/2, fusion_adacofnet.py:240) although its fused caller drops
-    # them (src/fusion_net/interpolate_twoframe.py:156,229-237).  A caller that does not need them sets this to False on
-    # the module: the sampler then skips their 24 B/px of stores and forward returns None in their place.
-    return_sides = True
-
-    def forward(self, frame0, frame2):
+    def forward(self, frame0, frame2, return_sides=True):
+        """The reference returns both sampled sides (tensorAdaCoF1/2, fusion_adacofnet.py:240) although its fused caller
+        drops them (src/fusion_net/interpolate_twoframe.py:156,229-237).  `return_sides=False` (a per-call argument, so
+        callers sharing the module never see each other's choice) makes the sampler skip their 24 B/px of stores; forward
+        then returns None in their place."""
         h0, w0 = int(frame0.shape[2]), int(frame0.shape[3])
         if h0 != int(frame2.shape[2]) or w0 != int(frame2.shape[3]):
             sys.exit("Frame sizes do not match")                                 # fusion_adacofnet.py:177-178
         pad0, pad2, x6 = ops.adacof_prepare(frame0.contiguous(), frame2.contiguous(), rgbx=True)
         w1, a1, b1, w2, a2, b2, occ = self.get_kernel.forward_x6(x6, softmax=False)
         t1, t2, frame1, mask = adacof_fused(pad0, pad2, w1, a1, b1, w2, a2, b2, occ, self.dilation, rgbx=True,
-                                            weights_are_logits=True, want_sides=self.return_sides)
+                                            weights_are_logits=True, want_sides=bool(return_sides))
         if x6.shape[2] != h0 or x6.shape[3] != w0:
             # the reference's width crop assigns tensorAdaCoF1 from tensorAdaCoF2 (fusion_adacofnet.py:225);
             # both are unused downstream -- we return the correctly cropped t1.

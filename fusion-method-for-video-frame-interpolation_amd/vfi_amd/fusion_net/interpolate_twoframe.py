@@ -60,7 +60,11 @@ class FusionInterpolator:
         self.device = torch.device(device) if device is not None else next(fusion_net.parameters()).device
         self.phase_net_state = phase_net_state
         self._per_size = {}
-        self._sides_model = getattr(adacof_model, "model", adacof_model)        # the AdaCoFNet behind the Model wrapper
+        # the fused path never uses the two sampled sides (:156,229-237): models whose forward takes the per-call
+        # `return_sides` argument (the fusion variant) skip their stores
+        import inspect
+        net = getattr(adacof_model, "model", adacof_model)                      # the AdaCoFNet behind the Model wrapper
+        self._adacof_kwargs = {"return_sides": False} if "return_sides" in inspect.signature(net.forward).parameters else {}
 
     def _state(self, h, w):
         key = (h, w)
@@ -83,16 +87,7 @@ class FusionInterpolator:
         nlev = pyr.height - 2
         lab1, lab2 = ops.rgb2lab(rgb_frame1), ops.rgb2lab(rgb_frame2)                  # :148-149
         f1, f2 = rgb_frame1.unsqueeze(0), rgb_frame2.unsqueeze(0)
-
-        # the fused path never uses the two sampled sides (:156,229-237): have the sampler skip their stores
-        keep = getattr(self._sides_model, "return_sides", None)
-        if keep is not None:
-            self._sides_model.return_sides = False
-        try:
-            return self._run(rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2)
-        finally:
-            if keep is not None:
-                self._sides_model.return_sides = keep
+        return self._run(rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2)
 
     def _run(self, rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2):
         h, w = rgb_frame1.shape[1:]
@@ -106,7 +101,7 @@ class FusionInterpolator:
 
         # AdaCoF #1 (rgb1, rgb2) (:156), #2 (rgb1, phase_pred) and #3 (phase_pred, rgb2) (:229-233) are independent of each
         # other: ONE batch of three samples (the deep, small U-Net levels fill the chip better)
-        _, _, three, masks = self.adacof(torch.cat((f1, f1, pp), 0), torch.cat((f2, pp, f2), 0))
+        _, _, three, masks = self.adacof(torch.cat((f1, f1, pp), 0), torch.cat((f2, pp, f2), 0), **self._adacof_kwargs)
         ada_pred, flow_var_map, between = three[:1], masks[:1], three[1:]              # (1,3,H,W), (1,1,H,W), (2,3,H,W)
 
         # uncertainty maps (:198-225)
@@ -132,7 +127,7 @@ class FusionInterpolator:
         ada_uncertainty = ops.absdiff(fd, ops.median_filter(fd, 50), 5.0, True)        # :221-225 (1,H,W)
 
         # base (:234-238): AdaCoF #4 on the two intermediate results
-        _, _, base, _ = self.adacof(between[:1], between[1:])
+        _, _, base, _ = self.adacof(between[:1], between[1:], **self._adacof_kwargs)
 
         out = {"phase_pred": pp, "ada_pred": ada_pred, "base": base, "flow_var_map": flow_var_map,
                "phase_uncertainty": phase_uncertainty, "ada_uncertainty": ada_uncertainty}
