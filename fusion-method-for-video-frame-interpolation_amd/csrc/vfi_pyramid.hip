@@ -59,7 +59,7 @@ struct vfi_pyr_plan {
     float *lo0 = nullptr, *hi0 = nullptr;   // [H][W] unshifted
     float *low_gain = nullptr;   // [hl][wl] lo0 * prod_j lomask_j on the low residual's window, unshifted
     int tpitch_max = 0;          // row pitch of T the workspace is sized for (W rounded up to 16)
-    std::map<int, const float2 *> wave_tw_rows, wave_tw_cols;   // engine length -> stage twiddles (vfi_wfft.h)
+    std::map<int, const float2 *> wave_tw[3];   // [pass kind] engine length -> stage twiddles (vfi_wfft.h)   // engine length -> stage twiddles (vfi_wfft.h)
     // workspace (complex64 unless noted)
     float2 *half0 = nullptr;     // N x H x (W/2+1)   R2C spectrum of the input / FFT of high on synthesis
     float2 *half_hi = nullptr;   // N x H x (W/2+1)   high-pass half spectrum (C2R input)
@@ -789,12 +789,15 @@ int get_fft(vfi_pyr_plan *p, int n, vfi::fft::Plan1D *out) {
 }
 
 // ---- wave engine (vfi_wfft.h) selection: engine length of a pass or 0, and its stage twiddles (built once per plan) ----
-int wave_twiddles(vfi_pyr_plan *p, bool cols, int M, const float2 **out) {
-    auto &cache = cols ? p->wave_tw_cols : p->wave_tw_rows;
+enum WavePass { kWaveRows = 0, kWaveAnaCols = 1, kWaveSynCols = 2 };
+int wave_twiddles(vfi_pyr_plan *p, WavePass kind, int M, const float2 **out) {
+    auto &cache = p->wave_tw[kind];
     auto it = cache.find(M);
     if (it == cache.end()) {
         std::vector<float2> tw(4096);
-        const int cnt = cols ? vfi::pyrw::cols_twiddles(M, tw.data(), (int)tw.size()) : vfi::pyrw::rows_twiddles(M, tw.data(), (int)tw.size());
+        const int cap = (int)tw.size();
+        const int cnt = kind == kWaveRows ? vfi::pyrw::rows_twiddles(M, tw.data(), cap)
+                                          : (kind == kWaveAnaCols ? vfi::pyrw::cols_twiddles(M, tw.data(), cap) : vfi::pyrw::syn_twiddles(M, tw.data(), cap));
         if (cnt < 0) return vfi::fail(VFI_ERR_UNSUPPORTED, "pyramid: no wave-engine twiddles for length %d", M);
         tw.resize(cnt > 0 ? cnt : 1);
         float2 *dev = nullptr;
@@ -806,17 +809,61 @@ int wave_twiddles(vfi_pyr_plan *p, bool cols, int M, const float2 **out) {
     return VFI_OK;
 }
 // tables of a pass on the wave engine; tb->M == 0 when the engine has no configuration for this length
-int wave_tables(vfi_pyr_plan *p, bool cols, const vfi::fft::Plan1D &pl, vfi::pyrw::Tables *tb) {
-    static const bool off = [] { const char *e = getenv("VFI_PYR_WAVE"); return e && e[0] == '0'; }();      // (A/B switch)
+int wave_tables(vfi_pyr_plan *p, WavePass kind, const vfi::fft::Plan1D &pl, vfi::pyrw::Tables *tb) {
+    // A/B switch: VFI_PYR_WAVE = bit mask of the passes that may run on the wave engine (1 rows, 2 analysis columns,
+    // 4 synthesis columns and plain column passes; default all, 0 = the generic LDS engine everywhere)
+    static const int allowed = [] { const char *e = getenv("VFI_PYR_WAVE"); return e ? atoi(e) : 7; }();
     *tb = vfi::pyrw::Tables{};
-    const int M = off ? 0 : (cols ? vfi::pyrw::cols_engine_length(pl.n, pl.bluestein ? pl.m : 0) : vfi::pyrw::rows_engine_length(pl.n, pl.bluestein ? pl.m : 0));
+    const bool off = !((allowed >> (int)kind) & 1);
+    const int M = off ? 0 : (kind != kWaveRows ? vfi::pyrw::cols_engine_length(pl.n, pl.bluestein ? pl.m : 0) : vfi::pyrw::rows_engine_length(pl.n, pl.bluestein ? pl.m : 0));
     if (!M) return VFI_OK;
-    const int rc = wave_twiddles(p, cols, M, &tb->tw);
+    const int rc = wave_twiddles(p, kind, M, &tb->tw);
     if (rc) return rc;
     tb->chirp = pl.chirp; tb->bfilt = pl.bfilt; tb->M = M; tb->n = pl.n; tb->bluestein = pl.bluestein;
     return VFI_OK;
 }
 inline int round_up16(int x) { return (x + 15) & ~15; }
+
+// debugging aid (VFI_PYR_CHECK=1): wait for the stream and count the NaNs of a device array
+void debug_scan(const void *dev, size_t floats, hipStream_t s, const char *what, int level) {
+    static const bool on = getenv("VFI_PYR_CHECK") != nullptr;
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    std::vector<float> host(floats);
+    (void)hipMemcpy(host.data(), dev, floats * sizeof(float), hipMemcpyDeviceToHost);
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < floats; ++i)
+        if (host[i] != host[i]) { if (!bad) first = i; ++bad; }
+    if (bad) fprintf(stderr, "[vfi_pyr check] %s level %d: %zu NaNs of %zu floats, first at %zu\n", what, level, bad, floats, first);
+}
+
+// one row / column pass of a plain 2-D transform: on the wave engine where it has a configuration for the length,
+// otherwise on the generic LDS engine
+int pass_rows(vfi_pyr_plan *p, const vfi::fft::Plan1D &pw, const void *src, void *dst, long long rows, int src_pitch, int dst_pitch,
+              vfi::fft::RowLoad load, vfi::fft::RowStore store, bool inverse, hipStream_t s) {
+    using namespace vfi::fft;
+    vfi::pyrw::Tables tb;
+    int rc = wave_tables(p, kWaveRows, pw, &tb);
+    if (rc) return rc;
+    if (tb.M && rows < (1LL << 31)) {
+        vfi::pyrw::GenRowsArgs a{tb, src, dst, (int)rows, src_pitch, dst_pitch, 1.0f};
+        return vfi::pyrw::launch_gen_rows(a, (int)load, (int)store, inverse, s);      // (RowLoad / RowStore == GenRowKind values)
+    }
+    RowArgs r{pw, src, dst, rows, src_pitch, dst_pitch, rows_per_group(pw, rows), 1.0f};
+    return launch_rows(r, load, store, inverse, s);
+}
+int pass_cols(vfi_pyr_plan *p, const vfi::fft::Plan1D &ph, float2 *data, int planes, int cols, int ld, bool inverse, hipStream_t s) {
+    using namespace vfi::fft;
+    vfi::pyrw::Tables tb;
+    int rc = wave_tables(p, kWaveSynCols, ph, &tb);
+    if (rc) return rc;
+    if (tb.M) {
+        vfi::pyrw::GenColsArgs a{tb, data, planes, cols, ld, 1.0f};
+        return vfi::pyrw::launch_gen_cols(a, inverse, s);
+    }
+    ColArgs c{ph, data, planes, cols, ld, cols_per_group(ph, cols), 1.0f};
+    return launch_cols(c, inverse, s);
+}
 
 // in-place complex 2-D transform of `planes` dense h x w arrays (un-normalised)
 int fft2d_c2c(vfi_pyr_plan *p, float2 *data, int planes, int h, int w, bool inverse, hipStream_t s) {
@@ -824,11 +871,8 @@ int fft2d_c2c(vfi_pyr_plan *p, float2 *data, int planes, int h, int w, bool inve
     Plan1D ph, pw;
     int rc;
     if ((rc = get_fft(p, h, &ph)) || (rc = get_fft(p, w, &pw))) return rc;
-    ColArgs c{ph, data, planes, w, w, cols_per_group(ph, w), 1.0f};
-    if ((rc = launch_cols(c, inverse, s))) return rc;
-    const long long rows = (long long)planes * h;
-    RowArgs r{pw, data, data, rows, w, w, rows_per_group(pw, rows), 1.0f};
-    return launch_rows(r, kLoadComplex, kStoreComplex, inverse, s);
+    if ((rc = pass_cols(p, ph, data, planes, w, w, inverse, s))) return rc;
+    return pass_rows(p, pw, data, data, (long long)planes * h, w, w, kLoadComplex, kStoreComplex, inverse, s);
 }
 // real H x W images -> half spectra N x H x (W/2+1)
 int fft2d_r2c(vfi_pyr_plan *p, const float *img, float2 *half, int N, hipStream_t s) {
@@ -837,11 +881,8 @@ int fft2d_r2c(vfi_pyr_plan *p, const float *img, float2 *half, int N, hipStream_
     int rc;
     if ((rc = get_fft(p, p->H, &ph)) || (rc = get_fft(p, p->W, &pw))) return rc;
     const int wh = p->W / 2 + 1;
-    const long long rows = (long long)N * p->H;
-    RowArgs r{pw, img, half, rows, p->W, wh, rows_per_group(pw, rows), 1.0f};
-    if ((rc = launch_rows(r, kLoadReal, kStoreHalf, false, s))) return rc;
-    ColArgs c{ph, half, N, wh, wh, cols_per_group(ph, wh), 1.0f};
-    return launch_cols(c, false, s);
+    if ((rc = pass_rows(p, pw, img, half, (long long)N * p->H, p->W, wh, kLoadReal, kStoreHalf, false, s))) return rc;
+    return pass_cols(p, ph, half, N, wh, wh, false, s);
 }
 // half spectra (destroyed) -> real images, un-normalised inverse
 int fft2d_c2r(vfi_pyr_plan *p, float2 *half, float *out, int N, hipStream_t s) {
@@ -850,11 +891,8 @@ int fft2d_c2r(vfi_pyr_plan *p, float2 *half, float *out, int N, hipStream_t s) {
     int rc;
     if ((rc = get_fft(p, p->H, &ph)) || (rc = get_fft(p, p->W, &pw))) return rc;
     const int wh = p->W / 2 + 1;
-    ColArgs c{ph, half, N, wh, wh, cols_per_group(ph, wh), 1.0f};
-    if ((rc = launch_cols(c, true, s))) return rc;
-    const long long rows = (long long)N * p->H;
-    RowArgs r{pw, half, out, rows, wh, p->W, rows_per_group(pw, rows), 1.0f};
-    return launch_rows(r, kLoadHalf, kStoreReal, true, s);
+    if ((rc = pass_cols(p, ph, half, N, wh, wh, true, s))) return rc;
+    return pass_rows(p, pw, half, out, (long long)N * p->H, wh, p->W, kLoadHalf, kStoreReal, true, s);
 }
 
 PlaneMap make_map(const int *plane_index, int level, int N, int nb, int flags) {
@@ -896,9 +934,10 @@ extern "C" int vfi_pyr_plan_create(int H, int W, int height, int nbands, double 
         for (int k = 0; k <= p->nlev && !rc; ++k) {
             vfi::pyrw::Tables tb;
             rc = get_fft(p, k < p->nlev ? p->lev[k].h : p->hl, &tmp);
-            if (!rc && k < p->nlev) rc = wave_tables(p, true, tmp, &tb);
+            if (!rc && k < p->nlev) rc = wave_tables(p, kWaveAnaCols, tmp, &tb);
+            if (!rc && k < p->nlev) rc = wave_tables(p, kWaveSynCols, tmp, &tb);
             if (!rc) rc = get_fft(p, k < p->nlev ? p->lev[k].w : p->wl, &tmp);
-            if (!rc && k < p->nlev) rc = wave_tables(p, false, tmp, &tb);
+            if (!rc && k < p->nlev) rc = wave_tables(p, kWaveRows, tmp, &tb);
         }
     }
     p->tpitch_max = round_up16(W);
@@ -909,6 +948,13 @@ extern "C" int vfi_pyr_plan_create(int H, int W, int height, int nbands, double 
     if (!rc) rc = dev_alloc(p, (void **)&p->lod[0], N * HW * sizeof(float2));
     if (!rc) rc = dev_alloc(p, (void **)&p->lod[1], N * HW * sizeof(float2));
     if (!rc) rc = dev_alloc(p, (void **)&p->amp_bits, kMaxLevels * 4 * sizeof(unsigned));
+    if (!rc && getenv("VFI_PYR_POISON")) {      // debugging aid: NaN-fill the workspace, so a read of anything not yet written shows
+        (void)hipMemset(p->half0, 0xff, N * half * sizeof(float2));
+        (void)hipMemset(p->half_hi, 0xff, N * half * sizeof(float2));
+        (void)hipMemset(p->bands, 0xff, N * nbands * HW * sizeof(float2));
+        (void)hipMemset(p->lod[0], 0xff, N * HW * sizeof(float2));
+        (void)hipMemset(p->lod[1], 0xff, N * HW * sizeof(float2));
+    }
     if (rc) {
         if (rc == VFI_ERR_NOMEM) vfi::set_error("vfi_pyr_plan_create: device allocation failed");
         vfi_pyr_plan_destroy(p);
@@ -1014,6 +1060,7 @@ static int pyr_analyze_impl(vfi_pyr_plan *p, const float *img, int N, float *hig
     if (amp_max && hipMemsetAsync(p->amp_bits, 0, sizeof(unsigned) * p->nlev * groups, s) != hipSuccess)
         return vfi::fail(VFI_ERR_LAUNCH, "vfi_pyr_analyze_max: memset");
     if ((rc = fft2d_r2c(p, img, p->half0, N, s))) return rc;
+    debug_scan(p->half0, (size_t)N * H * (W / 2 + 1) * 2, s, "half spectrum", -1);
     for (int k = 0; k < p->nlev; ++k) {
         const Level &L = p->lev[k];
         if (!((level_mask >> k) & 1ull)) continue;      // (the levels read the half spectrum directly: nothing to pass along)
@@ -1022,8 +1069,8 @@ static int pyr_analyze_impl(vfi_pyr_plan *p, const float *img, int N, float *hig
         using namespace vfi::fft;
         Plan1D ph, pw;
         vfi::pyrw::Tables tbh, tbw;
-        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw)) || (rc = wave_tables(p, true, ph, &tbh)) ||
-            (rc = wave_tables(p, false, pw, &tbw)))
+        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw)) || (rc = wave_tables(p, kWaveAnaCols, ph, &tbh)) ||
+            (rc = wave_tables(p, kWaveRows, pw, &tbw)))
             return rc;
         const int tpitch = tbh.M && tbw.M ? round_up16(L.w) : L.w;      // (the generic kernels address T densely)
         const PlaneMap pm = make_map(plane_index, k, N, nb, flags);
@@ -1031,6 +1078,7 @@ static int pyr_analyze_impl(vfi_pyr_plan *p, const float *img, int N, float *hig
         if (tbh.M) {
             vfi::pyrw::AnaColsArgs ca{tbh, p->half0, W / 2 + 1, H, L.P_a, p->bands, tpitch, N, L.h, L.w};
             if ((rc = vfi::pyrw::launch_ana_cols(ca, s))) return rc;
+            debug_scan(p->bands, (size_t)N * nb * L.h * tpitch * 2, s, "T after the wave column pass", k);
         } else {
             int tile, bpp;
             level_tiling(ph, L.w, &tile, &bpp);
@@ -1134,8 +1182,8 @@ extern "C" int vfi_pyr_synthesize(vfi_pyr_plan *p, const float *high, const floa
         using namespace vfi::fft;
         Plan1D ph, pw;
         vfi::pyrw::Tables tbh, tbw;
-        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw)) || (rc = wave_tables(p, true, ph, &tbh)) ||
-            (rc = wave_tables(p, false, pw, &tbw)))
+        if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw)) || (rc = wave_tables(p, kWaveSynCols, ph, &tbh)) ||
+            (rc = wave_tables(p, kWaveRows, pw, &tbw)))
             return rc;
         const int tpitch = tbh.M && tbw.M ? round_up16(L.w) : L.w;
         const PlaneMap pm = make_map(plane_index, k, N, nb, flags);

@@ -58,18 +58,38 @@ struct SynColsArgs {
     int N, h, w, h2, w2;
 };
 
+// plain passes (vfi_pyrw_passes.h): how a row pass reads / writes its rows
+enum GenRowKind { kGenComplex = 0, kGenReal = 1, kGenHalf = 2 };      // Half: the first n/2+1 entries of a Hermitian row
+struct GenRowsArgs {
+    Tables tb;                    // tb.n = row length
+    const void *src;
+    void *dst;
+    int rows, src_pitch, dst_pitch;   // rows of all planes together; pitches in elements
+    float scale;
+};
+struct GenColsArgs {
+    Tables tb;                    // tb.n = column length (rows of a plane); tables of the SYNTHESIS column configurations
+    float2 *data;                 // [planes][n][ld], transformed in place
+    int planes, cols, ld;
+    float scale;
+};
+
 // engine length that serves a transform of length n (n itself, or Bluestein's 2^k / 3*2^k length), 0 when the engine has
 // no configuration for it (the caller then uses the generic LDS engine of vfi_fft.h for that pass)
 int rows_engine_length(int n, int bluestein_m);
 int cols_engine_length(int n, int bluestein_m);
 // stage-twiddle table of an engine length (host side, double precision): entries as (cos, sin) floats
 int rows_twiddles(int M, float2 *out, int cap);     // -> number of entries, or -1
-int cols_twiddles(int M, float2 *out, int cap);
+int cols_twiddles(int M, float2 *out, int cap);     // analysis column pass
+int syn_twiddles(int M, float2 *out, int cap);      // synthesis column pass (same lengths as the analysis one)
 
 int launch_rows_polar(const RowsArgs &a, hipStream_t s);        // analysis rows  (coeff_to_values, src/train/pyramid.py:63-69)
 int launch_rows_from_polar(const RowsArgs &a, hipStream_t s);   // synthesis rows (values_to_coeff, src/train/pyramid.py:99-107)
 int launch_ana_cols(const AnaColsArgs &a, hipStream_t s);
 int launch_syn_cols(const SynColsArgs &a, hipStream_t s);
+// supported (load, store, direction): (real, half, forward) = R2C rows, (half, real, inverse) = C2R rows, (complex, complex, *)
+int launch_gen_rows(const GenRowsArgs &a, int load, int store, bool inverse, hipStream_t s);
+int launch_gen_cols(const GenColsArgs &a, bool inverse, hipStream_t s);
 
 }  // namespace pyrw
 }  // namespace vfi

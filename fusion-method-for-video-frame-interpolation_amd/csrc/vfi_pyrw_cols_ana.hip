@@ -13,10 +13,10 @@ namespace {
 template <class C>
 int ana_dispatch(const AnaColsArgs &a, hipStream_t s) {
     if (a.tb.bluestein) {
-        if constexpr (blu_capable(C::M)) return launch_cols<C, true>(ana_cols_kernel<C, true>, a, a.w, a.N * kBands, s);
+        if constexpr (blu_capable(C::M)) return launch_cols<C, true, ana_cols_kernel<C, true>>(a, a.w, a.N * kBands, s);
         return vfi::fail(VFI_ERR_UNSUPPORTED, "pyramid columns: engine length %d does not serve Bluestein", C::M);
     }
-    return launch_cols<C, false>(ana_cols_kernel<C, false>, a, a.w, a.N * kBands, s);
+    return launch_cols<C, false, ana_cols_kernel<C, false>>(a, a.w, a.N * kBands, s);
 }
 template <class C>
 int twiddles_of(float2 *out, int cap) {

@@ -2,6 +2,8 @@
 // instantiated for every column configuration of vfi_wfft_configs.h.
 #include "vfi_pyrw_kernels.h"
 
+#include <cmath>
+
 namespace vfi {
 namespace pyrw {
 
@@ -11,17 +13,37 @@ namespace {
 template <class C>
 int syn_dispatch(const SynColsArgs &a, hipStream_t s) {
     if (a.tb.bluestein) {
-        if constexpr (blu_capable(C::M)) return launch_cols<C, true>(syn_cols_kernel<C, true>, a, a.w, a.N, s);
+        if constexpr (blu_capable(C::M)) return launch_syn<C, true, syn_cols_kernel<C, true>>(a, s);
         return vfi::fail(VFI_ERR_UNSUPPORTED, "pyramid columns: engine length %d does not serve Bluestein", C::M);
     }
-    return launch_cols<C, false>(syn_cols_kernel<C, false>, a, a.w, a.N, s);
+    return launch_syn<C, false, syn_cols_kernel<C, false>>(a, s);
+}
+template <class C>
+int twiddles_of(float2 *out, int cap) {
+    if (C::TW > cap) return -1;
+    for_twiddles<C>([&](int idx, int e) {
+        const double ang = -2.0 * 3.14159265358979323846 * (double)e / (double)C::M;
+        out[idx] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    });
+    return C::TW;
 }
 }  // namespace
+
+// (the synthesis column configurations own fewer lines per wave than the analysis ones, so their radix order -- and with
+// it the stage twiddles -- may differ for the same length)
+int syn_twiddles(int M, float2 *out, int cap) {
+    switch (M) {
+#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return twiddles_of<VFI_COL_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(out, cap);
+        VFI_WFFT_SYN_CONFIGS(X)
+#undef X
+    }
+    return -1;
+}
 
 int launch_syn_cols(const SynColsArgs &a, hipStream_t s) {
     switch (a.tb.M) {
 #define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return syn_dispatch<VFI_COL_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, s);
-        VFI_WFFT_COL_CONFIGS(X)
+        VFI_WFFT_SYN_CONFIGS(X)
 #undef X
     }
     return vfi::fail(VFI_ERR_UNSUPPORTED, "pyramid columns: no engine configuration for length %d", a.tb.M);

@@ -38,6 +38,9 @@ template <class C, bool BLU> struct Lds {
         if (BLU) {
             for (int k = threadIdx.x; k < C::M; k += blockDim.x) b[k] = tb.bfilt[k];
             for (int k = threadIdx.x; k < tb.n; k += blockDim.x) c[k] = tb.chirp[k];
+            // the tail [n, M/2) is read (and multiplied with zero padding) by the lanes whose positions lie past the
+            // transform: it must hold finite numbers, not whatever the previous workgroup left in LDS
+            for (int k = tb.n + threadIdx.x; k < C::M / 2; k += blockDim.x) c[k] = make_float2(0.0f, 0.0f);
         }
         tw = t; bf = b; ch = c;
         ints = reinterpret_cast<int *>(c + (BLU ? C::M / 2 : 0));
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(kMaxThreads) void rows_polar_kernel(const RowsArgs 
             }
         } else {
             const rsrc_t rP = rsrc_of(a.phase + obase), rA = rsrc_of(a.amp + obase);
+            float bmax = 0.0f;      // largest amplitude this lane writes in this batch (one plane, hence one image group)
 #pragma unroll
             for (int q = 0; q < I::QL; ++q) {
                 int l, k;
@@ -156,13 +160,12 @@ __global__ __launch_bounds__(kMaxThreads) void rows_polar_kernel(const RowsArgs 
                     const float am = sqrtf(re * re + im * im);
                     st1(rP, vo, r * I::PL * 4, atan2f(im, re) * a.phase_scale);
                     st1(rA, vo, r * I::PL * 4, am);
-                    if (want_max) gmax[0] = valid ? fmaxf(gmax[0], am) : gmax[0];
+                    if (want_max) bmax = valid ? fmaxf(bmax, am) : bmax;
                 }
             }
-            if (want_max) {      // one plane per batch: fold the batch's maximum into its image group
+            if (want_max) {
 #pragma unroll
-                for (int t = 1; t < 4; ++t) gmax[t] = t == grp ? fmaxf(gmax[t], gmax[0]) : gmax[t];
-                if (grp != 0) gmax[0] = 0.0f;
+                for (int t = 0; t < 4; ++t) gmax[t] = t == grp ? fmaxf(gmax[t], bmax) : gmax[t];
             }
         }
     }
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(kMaxThreads) void rows_from_polar_kernel(const Rows
                     float sn, cs;
                     sincosf(ld1(rP, ve, r * I::T0 * 4), &sn, &cs);
                     const float am = ld1(rA, ve, r * I::T0 * 4);
-                    v[q * I::R0 + r] = fft::load_value<false>(make_float2(cs * am, sn * am), BLU ? m.ch[pos] : make_float2(0.0f, 0.0f), BLU);
+                    const float2 x = fft::load_value<false>(make_float2(cs * am, sn * am), BLU ? m.ch[pos] : make_float2(0.0f, 0.0f), BLU);
+                    v[q * I::R0 + r] = (!BLU || pos < n) ? x : make_float2(0.0f, 0.0f);
                 }
             }
         }
@@ -255,8 +259,9 @@ __global__ __launch_bounds__(kMaxThreads) void rows_from_polar_kernel(const Rows
 // (the bands of one column tile, then the next tile), so the 128-byte lines they share stay in one L2.
 __device__ __forceinline__ int xcd_item(int s, int per) { return (s & 7) * per + (s >> 3); }
 
+// (more than 48 values per lane: one wave per SIMD, which may then use the whole register file)
 template <class C, bool BLU>
-__global__ __launch_bounds__(kMaxThreads) void ana_cols_kernel(const AnaColsArgs a) {
+__global__ __launch_bounds__(C::E > 48 ? 256 : kMaxThreads) void ana_cols_kernel(const AnaColsArgs a) {
     using I = Io<C>;
     extern __shared__ float2 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(kMaxThreads) void ana_cols_kernel(const AnaColsArgs
     const int h = a.h, w = a.w, H = a.H, tilew = nw * C::L, ntile = (w + tilew - 1) / tilew;
     const int nitem = a.N * ntile * kBands, per = (nitem + 7) >> 3;
     const int hpos = h - h / 2;                                   // rows [0, hpos) hold fy >= 0
+    constexpr int RX = BLU ? I::R0_BLU : I::R0;                   // first-stage inputs that are loaded (the others are zero padding)
     for (int s = blockIdx.x; s < 8 * per; s += gridDim.x) {
         const int item = xcd_item(s, per);
         if (item >= nitem) continue;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(kMaxThreads) void ana_cols_kernel(const AnaColsArgs
             const unsigned vq = ok ? (unsigned)(i * w + col) * 4u : kOob;
 #pragma unroll
             for (int r = 0; r < I::R0; ++r) {
-                if (BLU && r >= I::R0_BLU) { v[q * I::R0 + r] = make_float2(0.0f, 0.0f); continue; }
+                if (r >= RX) { v[q * I::R0 + r] = make_float2(0.0f, 0.0f); continue; }
                 const int u = i + r * I::T0;                      // row of the level's window (unshifted order)
                 // row of the full-size half spectrum: fy = u (u < hpos) or u - h; mirrored (-fy) for the columns with fx < 0
                 const int U = neg ? (u < hpos ? (u == 0 ? 0 : H - u) : h - u) : (u < hpos ? u : u + (H - h));
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(kMaxThreads) void ana_cols_kernel(const AnaColsArgs
                 float2 z = ld2(rS, valid ? (unsigned)(U * a.spitch + sV) * 8u : kOob, 0);
                 const float g = ld1(rQ, valid ? vq : kOob, (unsigned)(r * I::T0) * (unsigned)w * 4u);
                 if (neg) z.y = -z.y;
-                // * i : (re, im) -> (-im, re); inverse transform: conjugate in
+                // * i : (re, im) -> (-im, re); inverse transform: conjugate in.  (Out-of-range loads returned 0.)
                 const float2 x = fft::load_value<true>(make_float2(-(z.y * g), z.x * g), BLU ? m.ch[u] : make_float2(0.0f, 0.0f), BLU);
                 v[q * I::R0 + r] = (!BLU || u < h) ? x : make_float2(0.0f, 0.0f);
             }
@@ -320,81 +326,97 @@ __global__ __launch_bounds__(kMaxThreads) void ana_cols_kernel(const AnaColsArgs
     }
 }
 
+// Workgroup = 4 waves = the four bands of the same L columns: every wave transforms its band's columns, multiplies by
+// its mask, and the four results are summed through LDS in a fixed order (band 0 + 1 + 2 + 3: deterministic); each wave
+// then adds the embedded coarser level to a quarter of the sums and stores them.
 template <class C, bool BLU>
-__global__ __launch_bounds__(kMaxThreads) void syn_cols_kernel(const SynColsArgs a) {
+__global__ __launch_bounds__(256, 2) void syn_cols_kernel(const SynColsArgs a) {
     using I = Io<C>;
+    static_assert(C::E * wfft::kWave <= C::XBUF, "the exchange buffer doubles as E x 64 scratch words");
     extern __shared__ float2 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    Lds<C, BLU> m(lds, a.tb, wave);
+    const int lane = threadIdx.x & 63, band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Lds<C, BLU> m(lds, a.tb, band);
+    const float *xall = m.xb - band * C::XBUF;                    // the four waves' buffers
     __syncthreads();
-    const int h = a.h, w = a.w, h2 = a.h2, w2 = a.w2, tilew = nw * C::L, ntile = (w + tilew - 1) / tilew;
+    const int h = a.h, w = a.w, h2 = a.h2, w2 = a.w2, ntile = (w + C::L - 1) / C::L;
     const int nitem = a.N * ntile, per = (nitem + 7) >> 3;
+    constexpr int EQ = (C::E + kBands - 1) / kBands;              // sums per wave
     for (int s = blockIdx.x; s < 8 * per; s += gridDim.x) {
         const int item = xcd_item(s, per);
-        if (item >= nitem) continue;
+        if (item >= nitem) continue;                              // (workgroup-uniform)
         const int tile = item % ntile, img = item / ntile;
-        const int col0 = tile * tilew + wave * C::L;
-        if (col0 >= w) continue;
-        const int col = col0 + lane % C::L;
+        const int col = tile * C::L + lane % C::L;
         const bool colok = col < w;
-        // the coarser level's window, embedded (reconstruct's `resdft`): this column's place in it
+        const rsrc_t rT = rsrc_of(a.T + (size_t)(img * kBands + band) * h * a.tpitch);
+        const rsrc_t rP = rsrc_of(a.P + (size_t)band * h * w);
+        float2 v[C::E];
+#pragma unroll
+        for (int q = 0; q < I::Q0; ++q) {
+            int l, i;
+            bool ok;
+            lane_index<C, 0>(lane, q, l, i, ok);
+            ok = ok && colok;
+            const unsigned vo = ok ? (unsigned)(i * a.tpitch + col) * 8u : kOob;
+#pragma unroll
+            for (int r = 0; r < I::R0; ++r) {
+                if (BLU && r >= I::R0_BLU) { v[q * I::R0 + r] = make_float2(0.0f, 0.0f); continue; }
+                const int u = i + r * I::T0;
+                const float2 x = fft::load_value<false>(ld2(rT, BLU && u >= h ? kOob : vo, (unsigned)(r * I::T0) * (unsigned)a.tpitch * 8u),
+                                                        BLU ? m.ch[u] : make_float2(0.0f, 0.0f), BLU);
+                v[q * I::R0 + r] = (!BLU || u < h) ? x : make_float2(0.0f, 0.0f);
+            }
+        }
+        transform<C, BLU>(v, lane, m);
+        // (-i) * FFTcol(T_b) * P_s[b], in place (0 wherever nothing is to be stored)
+#pragma unroll
+        for (int q = 0; q < I::QL; ++q) {
+            int l, k;
+            bool ok;
+            lane_index<C, I::SL>(lane, q, l, k, ok);
+            ok = ok && colok;
+            const unsigned vp = ok ? (unsigned)(k * w + col) * 4u : kOob;
+#pragma unroll
+            for (int r = 0; r < I::RL; ++r) {
+                const int u = k + r * I::PL;
+                const bool valid = ok && (!BLU || (r < I::RL_BLU && u < h));
+                const float2 z = fft::store_value<false>(v[q * I::RL + r], BLU ? m.ch[valid ? u : 0] : make_float2(0.0f, 0.0f), BLU);
+                const float ps = ld1(rP, valid ? vp : kOob, (unsigned)(r * I::PL) * (unsigned)w * 4u);
+                // * (-i) : (re, im) -> (im, -re)
+                v[q * I::RL + r] = valid ? make_float2(z.y * ps, -(z.x * ps)) : make_float2(0.0f, 0.0f);
+            }
+        }
+        // sum over the bands: element e = q * RL + r of lane `lane` sits at word e * 64 + lane of each wave's buffer
+        float2 sum[EQ];
+#pragma unroll
+        for (int comp = 0; comp < 2; ++comp) {
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) m.xb[e * wfft::kWave + lane] = comp ? v[e].y : v[e].x;
+            fft::lds_barrier();
+#pragma unroll
+            for (int j = 0; j < EQ; ++j) {
+                const float *x = xall + (kBands * j + band) * wfft::kWave + lane;      // (e = 4 j + band; e >= E reads scratch that is never stored)
+                const float t = ((x[0] + x[C::XBUF]) + x[2 * C::XBUF]) + x[3 * C::XBUF];
+                if (comp) sum[j].y = t; else sum[j].x = t;
+            }
+            fft::lds_barrier();
+        }
+        // + the coarser level's window, embedded (reconstruct's `resdft`), and out
         const int fx = signed_freq(colok ? col : 0, w);
         const bool xin = a.res != nullptr && fx >= -(w2 / 2) && fx <= w2 - w2 / 2 - 1;
         const int v2 = fx < 0 ? fx + w2 : fx;
         const rsrc_t rCur = rsrc_of(a.cur + (size_t)img * h * w);
         const rsrc_t rRes = rsrc_of(a.res ? a.res + (size_t)img * h2 * w2 : a.cur), rLo = rsrc_of(a.res ? a.lomask : a.P);
-#pragma unroll 1
-        for (int band = 0; band < kBands; ++band) {
-            const rsrc_t rT = rsrc_of(a.T + (size_t)(img * kBands + band) * h * a.tpitch);
-            const rsrc_t rP = rsrc_of(a.P + (size_t)band * h * w);
-            float2 v[C::E];
 #pragma unroll
-            for (int q = 0; q < I::Q0; ++q) {
-                int l, i;
-                bool ok;
-                lane_index<C, 0>(lane, q, l, i, ok);
-                ok = ok && colok;
-                const unsigned vo = ok ? (unsigned)(i * a.tpitch + col) * 8u : kOob;
-#pragma unroll
-                for (int r = 0; r < I::R0; ++r) {
-                    if (BLU && r >= I::R0_BLU) { v[q * I::R0 + r] = make_float2(0.0f, 0.0f); continue; }
-                    const int u = i + r * I::T0;
-                    const float2 x = fft::load_value<false>(ld2(rT, BLU && u >= h ? kOob : vo, (unsigned)(r * I::T0) * (unsigned)a.tpitch * 8u),
-                                                            BLU ? m.ch[u] : make_float2(0.0f, 0.0f), BLU);
-                    v[q * I::R0 + r] = (!BLU || u < h) ? x : make_float2(0.0f, 0.0f);
-                }
-            }
-            transform<C, BLU>(v, lane, m);
-#pragma unroll
-            for (int q = 0; q < I::QL; ++q) {
-                int l, k;
-                bool ok;
-                lane_index<C, I::SL>(lane, q, l, k, ok);
-                ok = ok && colok;
-                const unsigned vp = ok ? (unsigned)(k * w + col) * 4u : kOob;
-#pragma unroll
-                for (int r = 0; r < I::RL; ++r) {
-                    if (BLU && r >= I::RL_BLU) continue;
-                    const int u = k + r * I::PL;
-                    const bool valid = ok && (!BLU || u < h);
-                    const float2 z = fft::store_value<false>(v[q * I::RL + r], BLU ? m.ch[u] : make_float2(0.0f, 0.0f), BLU);
-                    const unsigned so = (unsigned)(r * I::PL) * (unsigned)w;
-                    const float ps = ld1(rP, valid ? vp : kOob, so * 4u);
-                    float2 acc;
-                    if (band == 0) {      // start of the sum: the embedded coarser level (0 outside its window)
-                        const int fy = signed_freq(u, h);
-                        const bool in = valid && xin && fy >= -(h2 / 2) && fy <= h2 - h2 / 2 - 1;
-                        const unsigned o2 = in ? (unsigned)((fy < 0 ? fy + h2 : fy) * w2 + v2) : kOob;
-                        const float2 rz = ld2(rRes, in ? o2 * 8u : kOob, 0);
-                        const float lom = ld1(rLo, in ? o2 * 4u : kOob, 0);
-                        acc = make_float2(rz.x * lom, rz.y * lom);
-                    } else {
-                        acc = ld2(rCur, valid ? vp * 2u : kOob, so * 8u);     // (this lane's own element of the previous band: L2)
-                    }
-                    // * (-i) : (re, im) -> (im, -re)
-                    st2(rCur, valid ? vp * 2u : kOob, so * 8u, make_float2(acc.x + z.y * ps, acc.y - z.x * ps));
-                }
-            }
+        for (int j = 0; j < EQ; ++j) {
+            const int e = kBands * j + band, q = e / I::RL, r = e - q * I::RL;      // (uniform)
+            const int id = lane + wfft::kWave * q, k = id / C::L, u = k + r * I::PL;     // (column mode: line = id % L = this lane's column)
+            const bool valid = e < C::E && id < C::NB(I::SL) && colok && u < h;
+            const int fy = signed_freq(valid ? u : 0, h);
+            const bool in = valid && xin && fy >= -(h2 / 2) && fy <= h2 - h2 / 2 - 1;
+            const unsigned o2 = (unsigned)((fy < 0 ? fy + h2 : fy) * w2 + v2);
+            const float2 rz = ld2(rRes, in ? o2 * 8u : kOob, 0);
+            const float lom = ld1(rLo, in ? o2 * 4u : kOob, 0);
+            st2(rCur, valid ? (unsigned)(u * w + col) * 8u : kOob, 0, make_float2(sum[j].x + rz.x * lom, sum[j].y + rz.y * lom));
         }
     }
 }
@@ -404,9 +426,10 @@ __global__ __launch_bounds__(kMaxThreads) void syn_cols_kernel(const SynColsArgs
 // =====================================================================================================================
 struct Occupancy { int blocks = 0, cus = 0; };
 
-// per kernel instantiation and device: raise the dynamic-LDS limit once, ask how many workgroups fit a CU
-template <typename K>
-inline Occupancy occupancy_of(K kernel, int threads, size_t lds) {
+// The kernel is a template ARGUMENT of every helper below, so each kernel instantiation has its own per-device cache
+// (keyed on the function-pointer type, kernels that share a signature would share -- and skip -- the LDS attribute).
+template <auto kernel>
+inline Occupancy occupancy_of(int threads, size_t lds) {
     Occupancy o;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o.blocks, kernel, threads, lds) != hipSuccess || o.blocks < 1) o.blocks = 1;
@@ -417,41 +440,34 @@ inline Occupancy occupancy_of(K kernel, int threads, size_t lds) {
     return o;
 }
 
-// waves per workgroup: the choice (4 or 8) that keeps more waves resident per CU (tables are per workgroup)
-template <class C, bool BLU, typename K>
-inline void pick_geometry(K kernel, int *threads, int *blocks_per_cu, int *cus) {
-    struct Pick { int threads = 0, blocks = 0, cus = 0; };
+struct Pick { int threads = 0, blocks = 0, cus = 0; };
+
+// row passes: waves per workgroup = the choice (4 or 8) that keeps more waves resident per CU (tables are per workgroup)
+template <class C, bool BLU, auto kernel, typename A>
+inline int launch_rows(const A &a, int nbatch, hipStream_t s) {
     static Pick cache[kMaxDevices];
     Pick &p = cache[current_device()];
     if (!p.threads) {
-        const Occupancy o4 = occupancy_of(kernel, 256, Lds<C, BLU>::bytes(4)), o8 = occupancy_of(kernel, 512, Lds<C, BLU>::bytes(8));
+        const Occupancy o4 = occupancy_of<kernel>(256, Lds<C, BLU>::bytes(4)), o8 = occupancy_of<kernel>(512, Lds<C, BLU>::bytes(8));
         if (o8.blocks * 8 > o4.blocks * 4) { p.threads = 512; p.blocks = o8.blocks; } else { p.threads = 256; p.blocks = o4.blocks; }
         p.cus = o4.cus;
     }
-    *threads = p.threads; *blocks_per_cu = p.blocks; *cus = p.cus;
-}
-
-template <class C, bool BLU, typename K, typename A>
-inline int launch_rows(K kernel, const A &a, int nbatch, hipStream_t s) {
-    int threads, bpc, cus;
-    pick_geometry<C, BLU>(kernel, &threads, &bpc, &cus);
-    const int nw = threads / 64;
+    const int nw = p.threads / 64;
     int grid = (nbatch + nw - 1) / nw;
-    if (grid > bpc * cus) grid = bpc * cus;
+    if (grid > p.blocks * p.cus) grid = p.blocks * p.cus;
     const size_t lds = Lds<C, BLU>::bytes(nw);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(p.threads), lds, s, a);
     return VFI_OK;
 }
 
 // column passes: 16 adjacent columns (one 128-byte line) per workgroup where the lines per wave allow it
-template <class C, bool BLU, typename K, typename A>
-inline int launch_cols(K kernel, const A &a, int w, int items_per_tile, hipStream_t s) {
-    struct Pick { int threads = 0, blocks = 0, cus = 0; };
+template <class C, bool BLU, auto kernel, typename A>
+inline int launch_cols(const A &a, int w, int items_per_tile, hipStream_t s) {
     static Pick cache[kMaxDevices];
     Pick &p = cache[current_device()];
     if (!p.threads) {
-        p.threads = C::L * 4 >= 16 ? 256 : 512;
-        const Occupancy o = occupancy_of(kernel, p.threads, Lds<C, BLU>::bytes(p.threads / 64));
+        p.threads = C::L * 4 >= 16 || C::E > 48 ? 256 : 512;
+        const Occupancy o = occupancy_of<kernel>(p.threads, Lds<C, BLU>::bytes(p.threads / 64));
         p.blocks = o.blocks; p.cus = o.cus;
     }
     const int nw = p.threads / 64, tilew = nw * C::L, ntile = (w + tilew - 1) / tilew;
@@ -461,6 +477,24 @@ inline int launch_cols(K kernel, const A &a, int w, int items_per_tile, hipStrea
     if (grid > cap) grid = cap;
     const size_t lds = Lds<C, BLU>::bytes(nw);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(p.threads), lds, s, a);
+    return VFI_OK;
+}
+
+// synthesis columns: a workgroup is the four bands of L columns
+template <class C, bool BLU, auto kernel>
+inline int launch_syn(const SynColsArgs &a, hipStream_t s) {
+    static Pick cache[kMaxDevices];
+    Pick &p = cache[current_device()];
+    const size_t lds = Lds<C, BLU>::bytes(kBands);
+    if (!p.blocks) {
+        const Occupancy o = occupancy_of<kernel>(256, lds);
+        p.blocks = o.blocks; p.cus = o.cus;
+    }
+    const int ntile = (a.w + C::L - 1) / C::L, nitem = a.N * ntile, per = (nitem + 7) / 8;
+    int grid = 8 * per;
+    const int cap = (p.blocks * p.cus) / 8 * 8;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, a);
     return VFI_OK;
 }
 

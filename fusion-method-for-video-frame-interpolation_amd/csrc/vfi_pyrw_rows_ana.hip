@@ -14,10 +14,10 @@ template <class C>
 int polar_dispatch(const RowsArgs &a, hipStream_t s) {
     const int nbatch = (a.planes * a.h + C::L - 1) / C::L;
     if (a.tb.bluestein) {
-        if constexpr (blu_capable(C::M)) return launch_rows<C, true>(rows_polar_kernel<C, true>, a, nbatch, s);
+        if constexpr (blu_capable(C::M)) return launch_rows<C, true, rows_polar_kernel<C, true>>(a, nbatch, s);
         return vfi::fail(VFI_ERR_UNSUPPORTED, "pyramid rows: engine length %d does not serve Bluestein", C::M);
     }
-    return launch_rows<C, false>(rows_polar_kernel<C, false>, a, nbatch, s);
+    return launch_rows<C, false, rows_polar_kernel<C, false>>(a, nbatch, s);
 }
 template <class C>
 int twiddles_of(float2 *out, int cap) {

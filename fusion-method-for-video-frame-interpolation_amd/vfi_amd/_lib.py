@@ -20,6 +20,7 @@ class VfiLibraryError(RuntimeError):
 
 # name -> argtypes.  tests/test_abi.py checks this table against include/vfi_hip.h.
 SIGNATURES = {
+    "vfi_debug_poison_lds": [c_s],
     "vfi_adacof_forward": [c_f] * 5 + [c_i] * 8 + [c_s],
     "vfi_adacof_fused": [c_f] * 13 + [c_i] * 6 + [c_s],
     "vfi_conv2d_packed_floats": [c_i] * 3,

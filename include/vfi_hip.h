@@ -52,6 +52,10 @@ typedef enum vfi_status {
 int vfi_abi_version(void);
 const char *vfi_status_string(int status);
 const char *vfi_last_error(void);
+/* Test aid (no reference counterpart): fills the LDS of every CU with NaNs, so that the kernels enqueued next on `stream`
+ * start on NaN-filled LDS -- a kernel whose result depends on LDS it has not written itself then shows deterministically
+ * (tests/test_pyramid_gpu.py::test_results_do_not_depend_on_stale_lds). */
+int vfi_debug_poison_lds(vfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * AdaCoF deformable sampling

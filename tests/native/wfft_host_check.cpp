@@ -163,6 +163,7 @@ int main() {
 #undef X
 #define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) check<Cfg<M, L, true, PITCH, P0, P1, P2, R0, R1, R2, R3>>("cols");
     VFI_WFFT_COL_CONFIGS(X)
+    VFI_WFFT_SYN_CONFIGS(X)
 #undef X
     std::printf(g_fail ? "FAIL: %d check(s)\n" : "all wave-engine checks passed (%d failures)\n", g_fail);
     return g_fail ? 1 : 0;

@@ -195,3 +195,33 @@ def test_round_trip_4k_levels_with_8192_point_bluestein(device):
     assert tuple(vals.phase[1].shape[2:]) == (1528, 2716)
     rec = pyr.inv_filter(vals)
     assert _psnr(rec.cpu(), img.cpu()) >= 90.0
+
+
+@pytest.mark.parametrize("h,w", [(128, 160), (90, 120), (256, 256)])
+def test_results_do_not_depend_on_stale_lds(h, w, device):
+    """LDS is not cleared between workgroups.  With every CU's LDS filled with NaNs right before each call, analysis and
+    synthesis (Bluestein levels included: their chirp tables have a tail that the zero-padding lanes read) must give the
+    same bits as without -- a kernel that reads LDS it has not written would return NaNs here, instead of once in a
+    while on a machine whose previous kernel happened to leave the wrong bytes behind."""
+    from vfi_amd import _lib
+    height = layout_cpu.calc_pyr_height(h, w)
+    img = _images(3, 1, h, w).to(device)
+    pyr = Pyramid(height, 4, S2, device)
+
+    def run(poison):
+        outs = []
+        for concat in (None, 2):
+            if poison:
+                _lib.call("vfi_debug_poison_lds", _lib.stream_ptr())
+            v = pyr.filter(img, concat_frames=concat) if concat is None else pyr.filter(img, concat_frames=concat, amp_max_eps=1e-8)[0]
+            outs += [v.high_level.clone(), v.low_level.clone()] + [p.clone() for p in v.phase] + [a.clone() for a in v.amplitude]
+            if concat is None:
+                if poison:
+                    _lib.call("vfi_debug_poison_lds", _lib.stream_ptr())
+                outs.append(pyr.inv_filter(v).clone())
+        return outs
+
+    clean, dirty = run(False), run(True)
+    for i, (a, b) in enumerate(zip(clean, dirty)):
+        assert not torch.isnan(b).any(), i
+        assert torch.equal(a, b), i

@@ -195,11 +195,13 @@ def simulate(g, pads, pitch, rng):
     raise AssertionError
 
 
-def lines_for(m, cols):
+def lines_for(m, cols, cap_e=None):
     """Lines one wave owns.  Row mode: L * M <= 2048 (<= 32 complex values per lane; the longest lengths take one row).
-    Column mode: as many adjacent columns (<= 16, i.e. up to 128-byte row segments) as keep the values per lane <= 48:
-    beyond that the column kernels (144+ data registers, plus the loads in flight) spill at two waves per SIMD."""
-    cap = 48 * 64 if cols else 2048
+    Column mode: as many adjacent columns (<= 16, i.e. up to 128-byte row segments) as keep the values per lane <= cap_e:
+    72 for the analysis columns (144 data registers: one wave per SIMD with the whole 512-register file, 4 columns =
+    32-byte row segments for the 1080-row level), 48 for the synthesis columns (two waves per SIMD: their workgroup is
+    the four bands of the same columns and meets at barriers)."""
+    cap = cap_e * 64 if cols else 2048
     l = 1
     while l < (16 if cols else 64) and 2 * l * m <= cap:
         l *= 2
@@ -220,17 +222,20 @@ def main():
     rng = np.random.default_rng(0)
     rows = []
     print("// GENERATED by tools/gen_wfft_configs.py -- do not edit; regenerate after changing the length lists there.")
-    print("// Geometry of the wave-private FFT engine (vfi_wfft.h): X(M, L, first-exchange pads..., pitch, radices...)")
+    print("// Geometry of the wave-private FFT engine (vfi_wfft.h): X(M, L, PITCH, PAD_0, PAD_1, PAD_2, radices...) for the row passes")
+    print("// (ROW), the analysis column pass (COL) and the synthesis column pass (SYN)")
     print("//   M = engine length, L = lines (rows / adjacent columns) one wave owns, PITCH = dwords between the lines of the")
     print("//   exchange buffer, PAD_s = pad dwords per block of P_(s+1) positions in the exchange after stage s.")
     print("#pragma once")
-    for cols, lengths, name in ((False, ROW_LENGTHS, "ROW"), (True, COL_LENGTHS, "COL")):
+    for cols, lengths, name, cap_e in ((False, ROW_LENGTHS, "ROW", None), (True, COL_LENGTHS, "COL", 72), (True, COL_LENGTHS, "SYN", 48)):
         entries = []
         for m in lengths:
-            lines = lines_for(m, cols)
+            lines = lines_for(m, cols, cap_e)
             seq = choose_radices(m, lines, cols, blu_capable(m))
             g = Geometry(m, lines, cols, seq)
             pads, pitch, cyc = choose_layout(g)
+            if cols and lines * pitch < g.e * WAVE:      # (the column kernels also use the buffer as E x 64 scratch words)
+                pitch += ((g.e * WAVE - lines * pitch + lines - 1) // lines + 31) // 32 * 32
             err = simulate(g, pads, pitch, rng)
             assert err < 1e-9, (m, seq, err)
             ideal = sum(q * r for q, r in zip(g.q, g.r)) - g.q[0] * g.r[0] if g.ns > 1 else 0
