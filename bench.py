@@ -7,8 +7,9 @@
 
 A step = ONE interpolated frame per rank (the whole sequence of reference
 src/fusion_net/interpolate_twoframe.py:148-330 with output_baseline, as src/evaluation always sets it:
-4x AdaCoF, 4 pyramid analyses, 5 syntheses, PhaseNet, uncertainty maps incl. the 50x50 median, FusionNet)
-on synthetic frame pairs already resident in HBM.  Frames of a clip shard across ranks with no data-path
+4x AdaCoF (three of them as one batch), 2 pyramid analyses + 2 syntheses + 2 radial-filter shortcuts (the reference's
+4 analyses and 5 syntheses, see vfi_pyr_apply_filter / _pair), PhaseNet, uncertainty maps incl. the 50x50 median,
+FusionNet) on synthetic frame pairs already resident in HBM.  Frames of a clip shard across ranks with no data-path
 collective (weak scaling: fixed work per GPU); weights are broadcast once from rank 0 over RCCL.
 Rank 0 prints ONE JSON line.
 
@@ -17,6 +18,7 @@ Rank 0 prints ONE JSON line.
 the child's code.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -86,19 +88,47 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(hw=(1080, 1920), runs=1, warmup_hw=(256, 256), threads=None):
-    """The oracle pipeline (CPU restatement of the same path, oracle/pipeline_cpu.py) on the benchmark workload ITSELF: one
-    fused frame with output_baseline at the benchmark size, on all host cores, after a small warm-up frame (thread pools,
-    first-touch); frames/s = 1 / median over `runs` timed runs.  One full-size run takes ~1.5 minutes on the GPU box's 16
-    host threads, so the default is ONE (a bounded sample of exactly the timed workload, nothing extrapolated); BASELINE.md's
-    "1 warm-up + 3 runs, median" protocol is `--cpu-baseline-runs 3` (its output is committed under profiles/).
-    A line per run goes to stderr so a long CPU leg never looks hung."""
-    from oracle import pipeline_cpu, synth
-    # the GPU box gives one GPU's job a 16-core share whatever os.cpu_count() says about the host: more threads than that
-    # only fight over the share (one 1080p frame then takes > 7 minutes instead of ~1.5)
+def usable_cores():
+    """Cores this process can actually run on at once: the affinity mask, cut down to the cgroup's CPU quota where one is
+    set (the GPU box gives one GPU's job a 16-core share of a much larger host; threads beyond the share only fight
+    over it -- a 1080p oracle frame then takes more than 7 minutes instead of ~70 s).  -> (cores, how they were found)"""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(threads or 16, avail))
+    how = f"sched_getaffinity: {avail}"
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # cgroup v1
+                q, p = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        how += f", cgroup cpu quota: {quota:g}"
+        avail = max(1, min(avail, int(quota + 0.5)))
+    elif avail > 32:
+        # no quota visible although the mask shows a whole host: stay at the share a one-GPU box is given
+        how += ", no cgroup quota visible: capped at the 16-core share of a one-GPU box"
+        avail = 16
+    return avail, how
+
+
+def cpu_baseline(hw=(1080, 1920), runs=3, warmup_hw=(256, 256), threads=None):
+    """The oracle pipeline (CPU restatement of the same path, oracle/pipeline_cpu.py) on the benchmark workload ITSELF: one
+    fused frame with output_baseline at the benchmark size after a small warm-up frame (thread pools, first-touch);
+    frames/s = 1 / median over `runs` timed runs -- BASELINE.md section 3's "1 warm-up + 3 runs, median" protocol by
+    default (~70 s per run on the GPU box's host share, so the CPU leg takes ~4 minutes).  Threads = every core this
+    process can use (usable_cores).  A line per run goes to stderr so a long CPU leg never looks hung."""
+    from oracle import pipeline_cpu, synth
+    avail, how = usable_cores()
+    threads = max(1, min(threads or avail, avail))
     torch.set_num_threads(threads)
+    print(f"[bench] cpu_baseline: {threads} threads ({how})", file=sys.stderr, flush=True)
     weights = pipeline_cpu.seeded_weights(0)
     w0, _, w2 = (torch.from_numpy(x) for x in synth.translating_pair(1, *warmup_hw))
     pipeline_cpu.interp(w0, w2, weights, output_baseline=True)
@@ -114,7 +144,8 @@ def cpu_baseline(hw=(1080, 1920), runs=1, warmup_hw=(256, 256), threads=None):
         print(f"[bench] cpu_baseline run {i + 1}/{runs}: {times[-1]:.1f} s", file=sys.stderr, flush=True)
     med = float(np.median(times))
     st = stages[int(np.argsort(times)[len(times) // 2])]
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "cores_note": f"all usable cores ({how})",
+            "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{runs} timed fused frame(s) at {w}x{h} (the benchmark workload itself) after a {warmup_hw[1]}x{warmup_hw[0]} "
                       f"warm-up frame; median {med:.1f} s of {[round(t, 1) for t in times]} on {threads} threads",
             "stage_seconds": {k: round(v, 3) for k, v in st.items()}}
@@ -138,19 +169,40 @@ def spawn_ranks(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+KERNEL_SOURCES = {"conv3x3_winograd4_kernel": "vfi_conv_winograd4.hip", "conv3x3_winograd_kernel": "vfi_conv_winograd.hip"}
+
+
+def kernel_source_hash(kernel):
+    """sha256[:16] of the source file a kernel lives in: the PMC passes behind `roofline.traffic` cannot run inside this
+    benchmark (they need separate rocprofv3 --pmc runs), so the committed figures carry the hash of the source they were
+    taken on and are dropped when the tree has moved on."""
+    src = KERNEL_SOURCES.get(kernel)
+    if not src:
+        return None
+    try:
+        with open(os.path.join(ROOT, "fusion-method-for-video-frame-interpolation_amd", "csrc", src), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def measured_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
-    runs of this benchmark, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes the file)."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    runs of this benchmark, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes the file) -- only
+    when they were taken on the kernel source of this tree."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             rows = json.load(f)
     except (OSError, ValueError):
-        return None, None
+        return None, {"source": TRAFFIC_FILE, "dropped": "file missing"}
     row = rows.get(kernel)
     if not row:
-        return None, None
-    return row["bytes_per_launch"], {"source": "profiles/r02_traffic.json", **{k: v for k, v in row.items() if k != "bytes_per_launch"}}
+        return None, {"source": TRAFFIC_FILE, "dropped": "no entry for this kernel"}
+    have = kernel_source_hash(kernel)
+    if row.get("kernel_source_sha16") != have:
+        return None, {"source": TRAFFIC_FILE, "dropped": f"counters were taken on source {row.get('kernel_source_sha16')}, the tree has {have}"}
+    return row["bytes_per_launch"], {"source": TRAFFIC_FILE, **{k: v for k, v in row.items() if k != "bytes_per_launch"}}
 
 
 def main():
@@ -165,8 +217,10 @@ def main():
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture each in-flight frame's ~700 launches into a hipGraph (torch.cuda.CUDAGraph) and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-runs", type=int, default=1,
-                    help="timed full-size runs of the CPU oracle (median reported); 3 = BASELINE.md's protocol, ~5 minutes")
+    ap.add_argument("--cpu-baseline-runs", type=int, default=3,
+                    help="timed full-size runs of the CPU oracle (median reported); 3 = BASELINE.md's protocol, ~4 minutes")
+    ap.add_argument("--steps-720p", type=int, default=20,
+                    help="extra timed steps at 1280x720 after the headline run (north_star asks for both sizes); 0 = skip")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -240,6 +294,26 @@ def main():
     elapsed = time.perf_counter() - t0
     frames, elapsed = shard.reduce_counters(args.steps, elapsed, device)
 
+    # second size north_star names: the same fused frame at 1280x720, same barriers, same in-flight scheme (eager)
+    value_720p = None
+    if args.steps_720p > 0 and (h, w) != (720, 1280):
+        pairs720 = synthetic_pairs(4, 720, 1280, device, seed=rank)
+
+        def step720(i):
+            f0, f2 = pairs720[i % len(pairs720)]
+            k = i % len(runners)
+            with torch.cuda.stream(streams[k]):
+                return runners[k](f0, f2, output_baseline=True)["final"]
+        for k in range(len(runners) + 2):      # plans / tables of the new size, then two warm-up frames
+            step720(k)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps_720p):
+            step720(i)
+        barrier()
+        f720, e720 = shard.reduce_counters(args.steps_720p, time.perf_counter() - t0, device)
+        value_720p = f720 / e720
+
     line = None
     if rank == 0:
         print(f"[bench] timed region: {frames} frames in {elapsed:.2f} s", file=sys.stderr, flush=True)
@@ -251,6 +325,9 @@ def main():
                            "frame": [h, w], "weights": f"random-init, {n_weights} params broadcast from rank 0",
                            "sharding": f"frame pairs over {world} rank(s), no data-path collective",
                            "frames_in_flight_per_gpu": args.streams, "hip_graph": bool(args.graph)}}
+        if value_720p is not None:
+            line["value_720p"] = value_720p
+            line["value_720p_note"] = f"same fused frame at 1280x720, {args.steps_720p} timed steps after the headline run, frames/s of all ranks"
         if not args.no_profile:
             # Per-kernel algorithmic work / measured launch duration: HIP events on the launch stream around every library
             # call, over ONE frame running ALONE on the device on one stream after the timed region.  (With two frames in
@@ -298,6 +375,13 @@ def main():
                 # (16 per 2x2 outputs and channel pair; directly: 36)
                 line["roofline"]["flops_counted"] = "Winograd F(2x2,3x3): 2*N*Cin*Cout*16*(H*W/4) per launch"
                 line["roofline"]["direct_conv_equivalent_tflops"] = tf * 2.25
+            # north_star's pyramid metric by name: the two pyramid entry points against the HBM roofline on their
+            # algorithmic bytes (72 * N * H * W bytes per call with all levels and both residuals)
+            line["roofline_pyramid"] = {
+                k: {"bound": "hbm", "achieved": v["work"] / v["seconds"] / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": v["work"] / v["seconds"] / 1e9 / PEAK_HBM_GBS, "calls_per_frame": v["calls"],
+                    "ms_per_frame": v["seconds"] * 1e3, "algorithmic_mb_per_call": v["work"] / v["calls"] / 1e6}
+                for k, v in agg.items() if k in ("pyr_analyze", "pyr_synthesize") and v["seconds"] > 0}
             line["roofline_other"] = []
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"]):
                 if k == dom or not v["kind"]:

@@ -505,6 +505,22 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
     return wide ? launch_conv<1, 8, 2>(a, N, s) : launch_conv<1, 8, 1>(a, N, s);
 }
 
+// Which kernel vfi_conv2d / vfi_conv2d_pool2 would run for a layer (labels and flop counts of profiling tools: the one
+// place the selection lives is here, next to the dispatch above).
+extern "C" int vfi_conv2d_algo(int N, int Cin, int H, int W, int Cout, int KS, int has_residual, int pooled, int act) {
+    if (N < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return VFI_ERR_INVALID_ARG;
+    static const bool wino_on = !(getenv("VFI_CONV_WINOGRAD") && atoi(getenv("VFI_CONV_WINOGRAD")) == 0);
+    ConvArgs a{};
+    a.Cin = Cin; a.Cout = Cout; a.Cout_pad = round_up(Cout, 32); a.H = H; a.W = W; a.act = act; a.tiles_x = vfi::ceil_div(W, 32);
+    static float dummy;
+    a.res = has_residual ? &dummy : nullptr;
+    a.pool = pooled ? &dummy : nullptr;
+    const long long wino_work_items = (long long)a.tiles_x * vfi::ceil_div(H, 8) * N * (a.Cout_pad / 32) * 16;
+    if (KS == 3 && wino_on && (long long)Cin * H * W * 4 < (1ll << 32) && wino_work_items < (1ll << 30))
+        return winograd4_suits(a, N) ? VFI_CONV_ALGO_WINOGRAD4 : VFI_CONV_ALGO_WINOGRAD2;
+    return VFI_CONV_ALGO_DIRECT;
+}
+
 extern "C" int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,
                           const float *residual, long long res_bstride, float *y, long long y_bstride, int N,
                           int Cin, int H, int W, int Cout, int KS, int pad_mode, int act, float *workspace,

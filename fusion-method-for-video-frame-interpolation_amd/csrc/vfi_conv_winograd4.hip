@@ -464,13 +464,24 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
     const long long items = (long long)vfi::ceil_div(a.W, T::TW) * vfi::ceil_div(a.H, T::TH) * N * (a.Cout_pad / T::BN);
     if (items >= (1ll << 28)) return false;
     if (mode == 2) return true;
-    // Measured per layer of the 1080p frame against the F(2x2) kernel (twice as many, shorter items; K split): 8-20 %
-    // faster from 2000 items up and where the items fill whole rounds of the 256 resident workgroups (1020, 1530: 4 and 6
-    // rounds; 216..510: one or two), slower where the last round is mostly empty (272, 544, 816) and for 6 -> 32 layers.
+    // Measured per layer of the 1080p frame against the F(2x2) kernel (twice as many, shorter items; K split) on a part
+    // with 256 CUs, i.e. 256 resident workgroups: 8-20 % faster from 7.8 rounds of items up (2000) and where the items
+    // fill whole rounds (1020 and 1530 items = 4 and 6 rounds; 216..510 = one or two), slower where the last round is
+    // mostly empty (272, 544, 816 items), between 6.25 and 7.8 rounds and at 3.4 rounds (1632 and 864 items: re-measured
+    // in round 3 with a pure "last round >= 84 % full" rule, +1.1 ms per frame) and for 6 -> 32 layers.  The windows are
+    // kept as measured, in units of rounds of the device's own CU count instead of item counts of that one part.
     if (a.Cin < 16) return false;
-    const long long rounds = (items + 255) / 256;
-    const bool full_rounds = items * 100 >= rounds * 256 * 84;
-    return items >= 2000 || (items >= 1000 && items < 1600) || (items <= 512 && items >= 200 && full_rounds);
+    static int cus_dev[vfi::kMaxDevices] = {};
+    int &cus = cus_dev[vfi::current_device()];
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    const long long rounds = (items + cus - 1) / cus;
+    const bool full_rounds = items * 100 >= rounds * cus * 84;
+    const long long r1000 = items * 1000 / cus;                  // rounds x 1000
+    return r1000 >= 7800 || (r1000 >= 3900 && r1000 < 6250) || (r1000 <= 2000 && r1000 >= 780 && full_rounds);
 }
 
 int vfi::conv::launch_winograd4(const ConvArgs &a, int N, hipStream_t s) {

@@ -86,11 +86,11 @@ __global__ void channel_mean_diff_kernel(const float *__restrict__ a, const floa
         out[i] = (clamp01 & 1) ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
     }
 }
-// out = |x - y| * scale, optionally clamped   (subtract_values: src/train/utils.py:322-346; :223-224)
+// out = |x - y| * scale (|x| * scale without y), optionally clamped   (subtract_values: src/train/utils.py:322-346; :223-224)
 __global__ void absdiff_kernel(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out,
                                long long total, float scale, int clamp01) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const float v = fabsf(x[i] - y[i]) * scale;
+        const float v = fabsf(y ? x[i] - y[i] : x[i]) * scale;
         out[i] = clamp01 ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
     }
 }
@@ -468,7 +468,7 @@ extern "C" int vfi_channel_mean_diff(const float *a, const float *b, float *out,
 
 extern "C" int vfi_absdiff(const float *x, const float *y, float *out, long long count, float scale, int clamp01,
                            vfi_stream_t stream) {
-    VFI_REQUIRE(x && y && out, VFI_ERR_INVALID_ARG, "vfi_absdiff: null pointer");
+    VFI_REQUIRE(x && out, VFI_ERR_INVALID_ARG, "vfi_absdiff: null pointer");      // (y == NULL: |x| * scale)
     VFI_REQUIRE(count > 0, VFI_ERR_INVALID_ARG, "vfi_absdiff: bad size");
     hipLaunchKernelGGL(absdiff_kernel, dim3(blocks_1d(count)), dim3(256), 0, vfi::as_stream(stream), x, y, out, count, scale, clamp01);
     return vfi::check_launch("vfi_absdiff");

@@ -24,6 +24,7 @@ SIGNATURES = {
     "vfi_adacof_forward": [c_f] * 5 + [c_i] * 8 + [c_s],
     "vfi_adacof_fused": [c_f] * 13 + [c_i] * 6 + [c_s],
     "vfi_conv2d_packed_floats": [c_i] * 3,
+    "vfi_conv2d_algo": [c_i] * 9,
     "vfi_conv2d_pack": [c_f] * 3 + [c_i] * 3 + [c_s],
     "vfi_conv2d": [c_f, c_l, c_f, c_f, c_f, c_l, c_f, c_l] + [c_i] * 8 + [c_f, c_l, c_s],
     "vfi_conv2d_pool2": [c_f, c_l, c_f, c_f, c_f, c_l, c_f, c_l, c_i] + [c_i] * 8 + [c_f, c_l, c_s],

@@ -85,14 +85,17 @@ class FusionInterpolator:
         h, w = rgb_frame1.shape[1:]
         pyr, phase_net = self._state(h, w)
         nlev = pyr.height - 2
-        lab1, lab2 = ops.rgb2lab(rgb_frame1), ops.rgb2lab(rgb_frame2)                  # :148-149
+        # both Lab frames in ONE (6,H,W) buffer: it is the pyramid's input (:172) and FusionNet's `other` (:324-325) as is
+        lab12 = torch.empty((6, h, w), dtype=torch.float32, device=rgb_frame1.device)
+        ops.rgb2lab(rgb_frame1, out=lab12[:3])                                         # :148-149
+        ops.rgb2lab(rgb_frame2, out=lab12[3:])
         f1, f2 = rgb_frame1.unsqueeze(0), rgb_frame2.unsqueeze(0)
-        return self._run(rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2)
+        return self._run(rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab12, f1, f2)
 
-    def _run(self, rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab1, lab2, f1, f2):
+    def _run(self, rgb_frame1, rgb_frame2, output_baseline, pyr, phase_net, nlev, lab12, f1, f2):
         h, w = rgb_frame1.shape[1:]
         # PhaseNet branch (:168-192)
-        vals, bufs, amp_max = pyr.filter(torch.cat((lab1, lab2), 0), concat_frames=2, phase_scale=1.0 / math.pi,
+        vals, bufs, amp_max = pyr.filter(lab12, concat_frames=2, phase_scale=1.0 / math.pi,
                                          amp_max_eps=phase_net.eps)       # (the per-level maxima of :55 come with the bands)
         vals_pred = phase_net(phase_net.normalize_vals(vals, concat=bufs, amp_max=amp_max))
         lab_pred = pyr.inv_filter(DecompValues(0, vals_pred.phase, vals_pred.amplitude, vals_pred.low_level))
@@ -111,8 +114,9 @@ class FusionInterpolator:
         # unmodified values, so 48 band FFTs collapse into one R2C / C2R pair on one image
         m = ops.channel_mean_diff(ada_pred, phase_pred.unsqueeze(0), 1.0, False, signed=True)      # (1,H,W)
         hf = pyr.band_filter(m, level_mask=1, keep_high=True)
-        d = ops.absdiff(hf, torch.zeros_like(hf), 100.0, True)                          # :210-211
-        phase_uncertainty = ops.gaussian_filter(d, 5)                                  # :212-214  (1,H,W)
+        maps = torch.empty((1, 3, h, w), dtype=torch.float32, device=rgb_frame1.device)   # :326-327, filled in place below
+        d = ops.absdiff(hf, None, 100.0, True)                                         # :210-211
+        phase_uncertainty = ops.gaussian_filter(d, 5, out=maps[:, 1])                  # :212-214  (1,H,W)
         # ada uncertainty (:217-225): |phase|,|amp| differences are not linear -> transform the 6 coarsest levels
         mask = ((1 << coarse) - 1) << (nlev - coarse)
         vb = pyr.filter(torch.cat((ada_pred[0], phase_pred), 0), level_mask=mask, want_high=False)   # 6 images, RGB space
@@ -124,7 +128,7 @@ class FusionInterpolator:
         dlow = ops.absdiff(vb.low_level[3:], vb.low_level[:3])
         freq = pyr.inv_filter(DecompValues(0, dp, da, dlow))                           # :217-219 (3,H,W)
         fd = ops.channel_mean_diff(freq.unsqueeze(0), None, 30.0, False)               # :220
-        ada_uncertainty = ops.absdiff(fd, ops.median_filter(fd, 50), 5.0, True)        # :221-225 (1,H,W)
+        ada_uncertainty = ops.absdiff(fd, ops.median_filter(fd, 50), 5.0, True, out=maps[:, 0])   # :221-225 (1,H,W)
 
         # base (:234-238): AdaCoF #4 on the two intermediate results
         _, _, base, _ = self.adacof(between[:1], between[1:], **self._adacof_kwargs)
@@ -141,8 +145,8 @@ class FusionInterpolator:
                                        ops.rgb2lab(phase_pred), dict(level_mask=fine, keep_low=True))
             out["baseline"] = ops.lab2rgb(lab).unsqueeze(0)
 
-        other = torch.cat((lab1, lab2), 0).unsqueeze(0)                                # :324-325 (1,6,H,W)
-        maps = torch.stack((ada_uncertainty, phase_uncertainty, flow_var_map[:, 0]), 1)   # :326-327 (1,3,H,W)
+        other = lab12.unsqueeze(0)                                                     # :324-325 (1,6,H,W)
+        maps[:, 2].copy_(flow_var_map[:, 0])                                           # (the sampler's mask comes with a batch of three)
         out["final"] = self.fusion_net(base, ada_pred, pp, other, maps, variant=0)     # :330
         return out
 

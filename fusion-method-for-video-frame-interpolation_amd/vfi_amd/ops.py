@@ -74,20 +74,16 @@ WINOGRAD = os.environ.get("VFI_CONV_WINOGRAD", "1") != "0"     # mirrors the lib
 FUSED_RESIZE = (not WINOGRAD) or os.environ.get("VFI_CONV_FUSED_RESIZE", "0") == "1"
 # (measured again in round 2 for the thin 25 -> 25 head convolutions alone: the fused loader loses there too,
 # 77.5 vs 72.2 ms per frame)
-WINOGRAD4 = int(os.environ.get("VFI_CONV_WINOGRAD4", "1"))     # mirrors csrc/vfi_conv_winograd4.hip: winograd4_suits (labels only)
-
-
 def _winograd_work(n, cin, cout, h, w, residual=False, pooled=False, act="relu"):
-    """Profiling label and the executed algorithm's own flop count of a 3x3 layer: F(4x4,3x3) -- 36 multiply-adds per 4x4
-    outputs and channel pair -- where the library picks that kernel (large layers), else F(2x2,3x3) -- 16 per 2x2."""
-    items = -(-w // 64) * -(-h // 16) * n * (-(-cout // 32))
-    rounds = -(-items // 256)
-    big = WINOGRAD4 == 2 or (WINOGRAD4 and cin >= 16 and (items >= 2000 or 1000 <= items < 1600
-                                                            or (200 <= items <= 512 and items * 100 >= rounds * 256 * 84)))
-    big = big and not (pooled and (residual or act != "relu"))
-    if big:
+    """Profiling label and the executed algorithm's own flop count of a 3x3 layer.  Which kernel runs is the library's
+    decision (vfi_conv2d_algo): F(4x4,3x3) -- 36 multiply-adds per 4x4 outputs and channel pair -- or F(2x2,3x3) -- 16 per
+    2x2 outputs."""
+    algo = _lib.lib().vfi_conv2d_algo(n, cin, h, w, cout, 3, int(bool(residual)), int(bool(pooled)), ACT[act])
+    if algo == 2:
         return ("flop", 2.0 * n * cin * cout * 36 * (h * w / 16.0), "conv3x3_winograd4_kernel")
-    return ("flop", 2.0 * n * cin * cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")
+    if algo == 1:
+        return ("flop", 2.0 * n * cin * cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")
+    return ("flop", 2.0 * n * cin * cout * 9 * h * w, "conv2d_mfma_kernel<3,8,%d>" % (2 if ((cout + 31) // 32 * 32) % 64 == 0 else 1))
 
 
 _WORKSPACES = {}
@@ -266,11 +262,21 @@ def tanh_residual_clamp(x, base):
     return out
 
 
-def rgb2lab(rgb):
+def _out_like(x, out, name):
+    """`out`: None (a new tensor) or a contiguous tensor of x's shape the op writes into (a slice of a wider buffer: no
+    concat copy afterwards)."""
+    if out is None:
+        return torch.empty_like(x)
+    if tuple(out.shape) != tuple(x.shape) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != x.device:
+        raise VfiLibraryError(f"{name}: out must be a contiguous float32 tensor of shape {tuple(x.shape)} on {x.device}")
+    return out
+
+
+def rgb2lab(rgb, out=None):
     """(N,3,H,W) or (3,H,W) rgb in [0,1] -> scaled Lab, same shape (reference src/train/transform.py:17-25)."""
     x = rgb.contiguous()
     hw = x.shape[-1] * x.shape[-2]
-    out = torch.empty_like(x)
+    out = _out_like(x, out, "rgb2lab")
     _lib.call("vfi_rgb2lab", _lib.dptr(x, "rgb"), out.data_ptr(), x.numel() // (3 * hw), hw, _lib.stream_ptr())
     return out
 
@@ -293,21 +299,24 @@ def channel_mean_diff(a, b=None, scale=1.0, clamp01=False, signed=False):
     return out
 
 
-def absdiff(x, y, scale=1.0, clamp01=False):
-    x, y = x.contiguous(), y.contiguous()
-    if x.shape != y.shape:
-        raise VfiLibraryError("absdiff: shape mismatch")
-    out = torch.empty_like(x)
-    _lib.call("vfi_absdiff", _lib.dptr(x, "x"), _lib.dptr(y, "y"), out.data_ptr(), x.numel(), float(scale),
-              int(bool(clamp01)), _lib.stream_ptr())
+def absdiff(x, y, scale=1.0, clamp01=False, out=None):
+    """|x - y| * scale, or |x| * scale for y=None (no zero tensor is built to subtract)."""
+    x = x.contiguous()
+    if y is not None:
+        y = y.contiguous()
+        if x.shape != y.shape:
+            raise VfiLibraryError("absdiff: shape mismatch")
+    out = _out_like(x, out, "absdiff")
+    _lib.call("vfi_absdiff", _lib.dptr(x, "x"), _lib.dptr(y, "y") if y is not None else None, out.data_ptr(), x.numel(),
+              float(scale), int(bool(clamp01)), _lib.stream_ptr())
     return out
 
 
-def gaussian_filter(x, sigma, truncate=4.0):
+def gaussian_filter(x, sigma, truncate=4.0, out=None):
     """scipy.ndimage.gaussian_filter per (H,W) image of x (N,H,W)."""
     x = x.contiguous()
     n, h, w = x.shape
-    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    tmp, out = torch.empty_like(x), _out_like(x, out, "gaussian_filter")
     _lib.call("vfi_gaussian_filter", _lib.dptr(x, "x"), tmp.data_ptr(), out.data_ptr(), n, h, w, float(sigma),
               float(truncate), _lib.stream_ptr())
     return out

@@ -45,7 +45,7 @@ typedef enum vfi_status {
     VFI_ERR_SHAPE = -2,       /* shape relation violated (mirrors the reference's asserts) */
     VFI_ERR_LAUNCH = -3,      /* HIP launch / runtime error */
     VFI_ERR_UNSUPPORTED = -4, /* valid request this build has no kernel for */
-    VFI_ERR_FFT = -5,         /* hipFFT plan / exec failure */
+    VFI_ERR_FFT = -5,         /* reserved (round 1 linked an FFT library; the transforms are hand-written kernels now) */
     VFI_ERR_NOMEM = -6        /* host or device allocation failed (plan creation only) */
 } vfi_status;
 
@@ -102,7 +102,8 @@ int vfi_adacof_fused_rgbx(const float *frame0_rgbx, const float *frame2_rgbx,
                           int N, int H, int W, int F, int dilation, int weights_are_logits, vfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * Dense convolution on the fp32 matrix cores (exact fp32, v_mfma_f32_32x32x2_f32)
+ * Dense convolution on the fp32 matrix cores (exact fp32: v_mfma_f32_16x16x4_f32 in the Winograd
+ * kernels that take the 3x3 layers, v_mfma_f32_32x32x2_f32 in the direct 1x1 / 5x5 kernels)
  * ---------------------------------------------------------------------------------- */
 
 typedef enum vfi_act {
@@ -130,8 +131,11 @@ int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int 
  * Replaces every nn.Conv2d (+ following BatchNorm / ReLU / ELU / Tanh / Sigmoid, + the additive U-Net
  * skip) on the path: reference src/phase_net/phase_net.py:190-200, src/fusion_net/fusion_adacofnet.py:18-155,
  * src/fusion_net/fusion_net.py:24-41,56-69.
- * KS = 3 runs Winograd on the fp32 matrix cores -- F(2x2,3x3), and F(4x4,3x3) for layers of 2000 or more 16x64 output
- * tiles x 32-channel blocks (same result up to fp32 rounding of the transforms: rms 3e-7 resp. 2e-6 of the output rms,
+ * KS = 3 runs Winograd on the fp32 matrix cores -- F(2x2,3x3), and F(4x4,3x3) for plain layers with Cin >= 16 whose work
+ * items (16x64 output tiles x 32-channel blocks) keep one workgroup per CU busy to the end: 7.8 or more rounds of the
+ * device's CU count, 3.9-6.25 rounds, or at most two rounds with the last one at least 84 % full (the windows measured
+ * per layer; vfi_conv2d_algo tells which kernel a layer gets; same result up to fp32 rounding
+ * of the transforms: rms 3e-7 resp. 2e-6 of the output rms,
  * <= 3e-5 resp. 1e-4 at worst on O(1) data; VFI_CONV_WINOGRAD4=0 in the environment keeps F(2x2) everywhere,
  * VFI_CONV_WINOGRAD=0 selects the direct kernel), KS = 1 / 5 the direct one.
  *   x        (N, Cin, H, W); consecutive samples are x_bstride floats apart, so x may be a channel
@@ -143,6 +147,12 @@ int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int 
  *            loop is split over several workgroups whose partial sums go through the workspace and are reduced
  *            in a fixed order (deterministic).  16 * N*Cout*H*W floats always suffice; results do not depend on
  *            whether a workspace is given beyond fp32 summation order. */
+enum { VFI_CONV_ALGO_DIRECT = 0, VFI_CONV_ALGO_WINOGRAD2 = 1, VFI_CONV_ALGO_WINOGRAD4 = 2 };
+/* Which kernel vfi_conv2d / vfi_conv2d_pool2 runs for a layer on the current device (>= 0: VFI_CONV_ALGO_*; < 0: status):
+ * direct implicit GEMM, Winograd F(2x2,3x3) or Winograd F(4x4,3x3).  For profiling labels and flop counts: the
+ * selection rule lives in the library only. */
+int vfi_conv2d_algo(int N, int Cin, int H, int W, int Cout, int KS, int has_residual, int pooled, int act);
+
 int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,
                const float *residual, long long res_bstride, float *y, long long y_bstride, int N, int Cin,
                int H, int W, int Cout, int KS, int pad_mode, int act, float *workspace,
@@ -244,12 +254,12 @@ int vfi_tanh_residual_clamp(const float *x, const float *base, float *y, long lo
  * Complex steerable pyramid (frequency domain), scale_factor-generalised
  * ---------------------------------------------------------------------------------- */
 
-/* Opaque plan: level geometry, mask tables, hipFFT plans and workspace for one
- * (H, W, height, nbands, scale_factor).  Replaces the per-frame construction of
- * `SCFpyr_PyTorch(height, nbands, scale_factor, device)` (reference src/train/pyramid.py:28-33,
- * rebuilt for every frame at src/fusion_net/interpolate_twoframe.py:124-129).  Creation allocates
- * device memory and synchronises; everything else only enqueues.  A plan is used from one host
- * thread at a time (hipFFT plans carry their stream). */
+/* Opaque plan: level geometry, mask tables, the tables of the hand-written FFT kernels (twiddles, Bluestein chirps and
+ * filters; no FFT library is linked) and workspace for one (H, W, height, nbands, scale_factor).  Replaces the
+ * per-frame construction of `SCFpyr_PyTorch(height, nbands, scale_factor, device)` (reference
+ * src/train/pyramid.py:28-33, rebuilt for every frame at src/fusion_net/interpolate_twoframe.py:124-129).  Creation
+ * allocates device memory and synchronises; everything else only enqueues.  A plan's workspace belongs to one stream
+ * at a time: frames in flight use one plan each. */
 typedef struct vfi_pyr_plan vfi_pyr_plan;
 
 enum {
@@ -257,8 +267,10 @@ enum {
     VFI_PYR_COMPLEX_COEFF = 2  /* bands are interleaved (re, im) coefficients instead of (phase, amplitude) */
 };
 
-/* Every level size must be transformable by the LDS FFT engine: any length with prime factors 2, 3, 5 up to 8704, any
- * other length up to 4096 (frames up to 3840x2160 qualify; VFI_ERR_UNSUPPORTED otherwise). */
+/* Every level size must be transformable: any length with prime factors 2, 3, 5 up to 8704, any other length up to 4096
+ * (frames up to 3840x2160 qualify; VFI_ERR_UNSUPPORTED otherwise).  Lengths the wave-private register engine has a
+ * configuration for (the level sizes of 256x256 ... 1920x1080 frames among them) run on it, the others on the generic
+ * LDS engine; results agree to fp32 rounding. */
 int vfi_pyr_plan_create(int H, int W, int height, int nbands, double scale_factor, int max_images,
                         vfi_pyr_plan **out);
 int vfi_pyr_plan_destroy(vfi_pyr_plan *plan);
@@ -332,7 +344,7 @@ int vfi_lab2rgb(const float *lab, float *rgb, int N, int HW, vfi_stream_t stream
 int vfi_channel_mean_diff(const float *a, const float *b, float *out, int N, int C, int HW, float scale,
                           int clamp01, vfi_stream_t stream);
 
-/* out = |x - y| * scale (clamped to [0,1] if clamp01): subtract_values (src/train/utils.py:322-346) and
+/* out = |x - y| * scale, or |x| * scale when y is NULL (clamped to [0,1] if clamp01): subtract_values (src/train/utils.py:322-346) and
  * `abs(freq_diff - median) * 5` clamp (interpolate_twoframe.py:223-224). */
 int vfi_absdiff(const float *x, const float *y, float *out, long long count, float scale, int clamp01,
                 vfi_stream_t stream);

@@ -214,8 +214,9 @@ def blu_capable(m):
     return m in (1, 3)
 
 
-ROW_LENGTHS = [3072, 2048, 1920, 1536, 1280, 1024, 960, 768, 640, 512, 480, 384, 320, 256, 240, 192, 160, 128, 120, 96, 64]
-COL_LENGTHS = [1536, 1080, 1024, 768, 720, 540, 512, 384, 360, 270, 256, 192, 180, 135, 128, 96, 90, 64]
+ROW_LENGTHS = [3072, 2048, 1920, 1536, 1280, 1024, 960, 768, 640, 512, 480, 384, 320, 256, 240, 192, 160, 128, 120, 96, 80, 64, 60, 48,
+               45, 40, 32, 30, 24, 20, 16, 15, 12]
+COL_LENGTHS = [1536, 1080, 1024, 768, 720, 540, 512, 384, 360, 270, 256, 192, 180, 135, 128, 96, 90, 64, 48, 45, 32, 24, 16, 12]
 
 
 def main():

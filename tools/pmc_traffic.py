@@ -12,10 +12,20 @@ Both the raw and the corrected figure are written.
 import argparse
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# source file of each kernel: bench.py only reports the traffic while the tree still holds the source the counters were taken on
+KERNEL_SOURCES = {"conv3x3_winograd4_kernel": "vfi_conv_winograd4.hip", "conv3x3_winograd_kernel": "vfi_conv_winograd.hip"}
+
+
+def source_hash(label):
+    with open(os.path.join(ROOT, "fusion-method-for-video-frame-interpolation_amd", "csrc", KERNEL_SOURCES[label]), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 csv.field_size_limit(sys.maxsize)
 
@@ -55,7 +65,8 @@ def main():
         fetch_b, write_b = fk * 1024.0 / fl, wk * 1024.0 / wl
         out[label] = {"bytes_per_launch": 2.0 * fetch_b + write_b, "fetch_size_bytes_per_launch_raw": fetch_b,
                       "write_size_bytes_per_launch": write_b, "fetch_correction": "x2 (gfx950: 16-B-per-lane streams tallied at half)",
-                      "launches_fetch_pass": fl, "launches_write_pass": wl, "command": args.command}
+                      "launches_fetch_pass": fl, "launches_write_pass": wl, "command": args.command,
+                      "kernel_source_sha16": source_hash(label)}
     text = json.dumps(out, indent=1)
     print(text)
     if args.out:
