@@ -79,6 +79,32 @@ __device__ __forceinline__ void st1(rsrc_t r, unsigned voff, unsigned soff, floa
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
+// ---- polar conversion on the hardware's fast paths -----------------------------------------------------------------------
+// atan2 of libm costs ~55 instructions and a dozen registers per coefficient -- as much as a whole FFT stage.  Here:
+// a = min/max through v_rcp_f32, atan(a) = a * p(a^2) with a degree-8 polynomial (fitted to minimise the absolute error of
+// a * p: 9.2e-8 in fp32 evaluation on [0, 1], tools/gen_wfft_configs.py's sibling one-liner in DESIGN.md section 7), then the
+// octant fix-ups; <= 3e-7 rad absolute, i.e. one ulp of pi.  atan2(+-0, x < 0) = +-pi and atan2(0, 0) = 0 as in libm.
+__device__ __forceinline__ float fast_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y), mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
+    const float s = a * a;
+    float p = 0.0024566983338445425f;
+    p = fmaf(p, s, -0.01440124586224556f);
+    p = fmaf(p, s, 0.03978102654218674f);
+    p = fmaf(p, s, -0.07234838604927063f);
+    p = fmaf(p, s, 0.10498936474323273f);
+    p = fmaf(p, s, -0.14161226153373718f);
+    p = fmaf(p, s, 0.19985906779766083f);
+    p = fmaf(p, s, -0.33332598209381104f);
+    p = fmaf(p, s, 0.9999998807907104f);
+    float r = a * p;
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.0f ? 3.14159265358979323846f - r : r;
+    return copysignf(r, y);
+}
+// |z| through v_sqrt_f32 (1 ulp; libm's correctly rounded sqrtf adds a Newton step and denormal scaling per coefficient)
+__device__ __forceinline__ float fast_hypot(float re, float im) { return __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)); }
+
 template <class C, bool BLU>
 __device__ __forceinline__ void transform(float2 (&v)[C::E], int lane, const Lds<C, BLU> &m) {
     forward<C>(v, lane, m.xb, m.tw);
@@ -157,8 +183,8 @@ __global__ __launch_bounds__(kMaxThreads) void rows_polar_kernel(const RowsArgs 
                     const float re = z.x * a.inv_hw, im = z.y * a.inv_hw;
                     const bool valid = ok && (!BLU || pos < n);
                     const unsigned vo = valid ? (unsigned)(l * n + k) * 4u : kOob;
-                    const float am = sqrtf(re * re + im * im);
-                    st1(rP, vo, r * I::PL * 4, atan2f(im, re) * a.phase_scale);
+                    const float am = fast_hypot(re, im);
+                    st1(rP, vo, r * I::PL * 4, fast_atan2(im, re) * a.phase_scale);
                     st1(rA, vo, r * I::PL * 4, am);
                     if (want_max) bmax = valid ? fmaxf(bmax, am) : bmax;
                 }
@@ -225,8 +251,10 @@ __global__ __launch_bounds__(kMaxThreads) void rows_from_polar_kernel(const Rows
                     if (BLU && r >= I::R0_BLU) { v[q * I::R0 + r] = make_float2(0.0f, 0.0f); continue; }
                     const int pos = i + r * I::T0;
                     const unsigned ve = BLU && pos >= n ? kOob : vo;          // (positions past the row read 0: amplitude 0)
-                    float sn, cs;
-                    sincosf(ld1(rP, ve, r * I::T0 * 4), &sn, &cs);
+                    // sin / cos on the hardware units (v_sin_f32 / v_cos_f32: absolute error <= 4e-7 for the phases of a pyramid,
+                    // |p| <= a few pi; libm's sincosf carries a Payne-Hanek path and ~40 registers into the load phase)
+                    const float ph = ld1(rP, ve, r * I::T0 * 4);
+                    const float sn = __sinf(ph), cs = __cosf(ph);
                     const float am = ld1(rA, ve, r * I::T0 * 4);
                     const float2 x = fft::load_value<false>(make_float2(cs * am, sn * am), BLU ? m.ch[pos] : make_float2(0.0f, 0.0f), BLU);
                     v[q * I::R0 + r] = (!BLU || pos < n) ? x : make_float2(0.0f, 0.0f);

@@ -1,12 +1,35 @@
 #!/bin/bash
-# Regenerates the bench lines and rocprofv3 kernel statistics kept under profiles/ (run on the GPU box, from the repo root;
-# results land in gpurun_out/ and are copied to profiles/ by hand).
+# Regenerates the bench lines, rocprofv3 kernel statistics and PMC traffic kept under profiles/ (run on the GPU box, from
+# the repo root: `gpurun -- bash tools/refresh_profiles.sh`; results land in gpurun_out/ and are copied to profiles/ by hand).
+# Every step appends to gpurun_out/refresh.log so a long run never looks silent.
 set -e
 cd "${GRAFT_REPO_ROOT:-.}"
-python bench.py > gpurun_out/r02_bench_default.json
-python bench.py --height 720 --width 1280 --no-cpu-baseline > gpurun_out/r02_bench_720p.json
+R=r03
+mkdir -p gpurun_out
+log() { echo "[$(date +%T)] $*" | tee -a gpurun_out/refresh.log; }
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof3 -o p3 -- python3 bench.py --no-cpu-baseline --steps 10 > gpurun_out/r02_bench_default_under_rocprof.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof1 -o p1 -- python3 bench.py --no-cpu-baseline --steps 10 --streams 1 > gpurun_out/r02_bench_streams1_under_rocprof.json
-find gpurun_out/prof3 gpurun_out/prof1 -name "*kernel_stats.csv" | xargs ls -la
+log "bench default (3 CPU runs)"
+python bench.py > gpurun_out/${R}_bench_default.json 2>> gpurun_out/refresh.log
+log "bench --streams 1 under rocprofv3 --kernel-trace --stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof1 -o p1 -- python3 bench.py --no-cpu-baseline --steps 10 --streams 1 --steps-720p 0 > gpurun_out/${R}_bench_streams1_under_rocprof.json 2>> gpurun_out/refresh.log
+log "bench default under rocprofv3 --kernel-trace --stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof3 -o p3 -- python3 bench.py --no-cpu-baseline --steps 10 --steps-720p 0 > gpurun_out/${R}_bench_default_under_rocprof.json 2>> gpurun_out/refresh.log
+cp "$(find gpurun_out/prof1 -name '*kernel_stats.csv' | head -1)" gpurun_out/${R}_bench_streams1_kernel_stats.csv
+cp "$(find gpurun_out/prof3 -name '*kernel_stats.csv' | head -1)" gpurun_out/${R}_bench_default_kernel_stats.csv
 find gpurun_out/prof3 gpurun_out/prof1 -name "*kernel_trace.csv" -delete
+log "PMC passes (separate runs, counters only): FETCH_SIZE, WRITE_SIZE"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --streams 1 --steps-720p 0 --no-profile > /dev/null 2>> gpurun_out/refresh.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --streams 1 --steps-720p 0 --no-profile > /dev/null 2>> gpurun_out/refresh.log
+python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --out gpurun_out/${R}_traffic.json \
+    --command "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --streams 1 --steps-720p 0 --no-profile" >> gpurun_out/refresh.log
+find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*counter_collection.csv" -delete
+log "pyramid kernels"
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pyrprof -o pp -- python3 tools/pyramid_bench.py > gpurun_out/${R}_pyramid_bench_under_rocprof.txt 2>> gpurun_out/refresh.log
+python3 tools/pyr_kernel_table.py "$(find gpurun_out/pyrprof -name '*kernel_trace.csv' | head -1)" 40 > gpurun_out/${R}_pyramid_kernel_table.txt
+find gpurun_out/pyrprof -name "*kernel_trace.csv" -delete
+python3 tools/pyramid_bench.py > gpurun_out/${R}_pyramid_bench.txt 2>> gpurun_out/refresh.log
+log "host enqueue time per frame (eager) and two ranks on one GPU over RCCL"
+python3 tools/probes/enqueue_time.py > gpurun_out/${R}_enqueue_time.txt 2>> gpurun_out/refresh.log
+# (RCCL refuses two ranks on one device -- "Duplicate GPU detected" -- so the one-GPU rehearsal of the N = 2 path runs on gloo)
+VFI_BENCH_SHARE_GPUS=1 VFI_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 6 --warmup 2 --steps-720p 0 --no-profile > gpurun_out/${R}_bench_2ranks_one_gpu_gloo.json 2>> gpurun_out/refresh.log || log "2-rank rehearsal failed"
+log done
