@@ -65,3 +65,18 @@ def test_no_cpu_fallback():
     w = torch.zeros(1, 25, 4, 4)
     with pytest.raises(NotImplementedError):   # reference adacof.py:356-357
         FunctionAdaCoF.apply(x, w, w, w, 1)
+
+
+def test_conv_algorithm_query_reports_the_library_rule():
+    """vfi_conv2d_algo is the one place the convolution selection lives (profiling labels query it instead of restating
+    it).  Without a GPU the library assumes 256 CUs, the part the windows were measured on: the query must reproduce them."""
+    h = vfi_amd.lib()
+    direct, wino2, wino4 = 0, 1, 2
+    assert h.vfi_conv2d_algo(1, 32, 1088, 1920, 3, 5, 0, 0, 1) == direct          # 5x5: direct implicit GEMM
+    assert h.vfi_conv2d_algo(1, 64, 1088, 1920, 64, 1, 0, 0, 0) == direct         # 1x1
+    assert h.vfi_conv2d_algo(3, 64, 544, 960, 64, 3, 0, 0, 1) == wino4            # 3060 items: >= 7.8 rounds of 256 CUs
+    assert h.vfi_conv2d_algo(1, 6, 1088, 1920, 32, 3, 0, 0, 1) == wino2           # Cin < 16
+    assert h.vfi_conv2d_algo(3, 128, 272, 480, 128, 3, 0, 0, 1) == wino2          # 1632 items: 6.4 rounds, between the windows
+    assert h.vfi_conv2d_algo(1, 64, 544, 960, 64, 3, 0, 0, 1) == wino4            # 1020 items: four full rounds
+    assert h.vfi_conv2d_algo(1, 128, 272, 480, 128, 3, 0, 0, 1) == wino2          # 544 items: last round mostly empty
+    assert h.vfi_conv2d_algo(0, 64, 64, 64, 64, 3, 0, 0, 1) < 0                   # bad arguments: a status, not an algorithm
