@@ -124,6 +124,15 @@ def test_evaluate_driver_on_a_tiny_testset(tmp_path, device):
     args_m = evl.parser.parse_args(argv + ["--middle_frame_target", "--test_sets", "ClipA"])
     mid = np.array(evl.evaluate_dataset(args_m, "ClipA"))
     assert mid.shape == (3, 4, 7) and not np.allclose(mid[:, 2, 2], res["ClipA"][:, 2, 2])
+    # a set without predictions raises (the reference's IndexError) and leaves NO cache entry behind: an empty array saved
+    # as result_<set>.npy would be taken for a result by every later run
+    (root / "ClipC").mkdir()                                   # too few frames: nothing gets interpolated
+    Image.fromarray(frames[("ClipA", 0)]).save(root / "ClipC" / "000.png")
+    argv_c = [a if a not in ("ClipA", "ClipB") else "ClipC" for a in argv]
+    argv_c = argv_c[:argv_c.index("--test_sets") + 2] + argv_c[argv_c.index("--test_sets") + 3:]      # one test set
+    with pytest.raises(IndexError):
+        evl.eval(evl.parser.parse_args(argv_c), rank=0, world=1)
+    assert not (tmp_path / "Eval" / "result_ClipC.npy").exists()
     pred = np.array(Image.open(tmp_path / "Eval" / "interpolated" / "ClipA" / "fusion" / "0001.png")).astype(np.float64) / 255
     d = pred - (frames[("ClipA", 1)].astype(np.float64) / 255)[4:68, 20:84]
     assert abs(mid[0, 2, 2] - 10 * np.log10(1.0 / ((d ** 2).mean() + 1e-8))) <= 1e-3

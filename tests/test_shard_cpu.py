@@ -63,3 +63,15 @@ def test_two_rank_gloo_broadcast_shard_and_reduce():
     assert a["pairs"] == [0, 1, 2, 3] and b["pairs"] == [4, 5, 6]
     assert a["vals"] == [0.5, 1.5, 2.5, 3.5] and b["vals"] == [4.5, 5.5, 6.5]
     assert a["total"] == b["total"] == 7 and a["tmax"] == b["tmax"] == 2.0
+
+
+def test_evaluate_needs_an_explicit_base_dir_under_several_ranks(monkeypatch):
+    """vfi_amd.evaluation.evaluate under torchrun: the default --base_dir embeds each process's start time, so the ranks
+    would write to different folders -- refused before anything touches a GPU; rank r runs on GPU LOCAL_RANK."""
+    import pytest
+    from vfi_amd.evaluation import evaluate as evl
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="base_dir"):
+        evl.eval(evl.parser.parse_args(["--fusion"]))
