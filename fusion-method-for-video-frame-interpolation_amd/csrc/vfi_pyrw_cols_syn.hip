@@ -7,7 +7,7 @@
 namespace vfi {
 namespace pyrw {
 
-#define VFI_COL_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, true, PITCH, P0, P1, P2, R0, R1, R2, R3>
+#define VFI_COL_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, TEAM, true, PITCH, P0, P1, P2, R0, R1, R2, R3>
 
 namespace {
 template <class C>
@@ -33,7 +33,7 @@ int twiddles_of(float2 *out, int cap) {
 // it the stage twiddles -- may differ for the same length)
 int syn_twiddles(int M, float2 *out, int cap) {
     switch (M) {
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return twiddles_of<VFI_COL_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(out, cap);
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return twiddles_of<VFI_COL_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3)>(out, cap);
         VFI_WFFT_SYN_CONFIGS(X)
 #undef X
     }
@@ -42,7 +42,7 @@ int syn_twiddles(int M, float2 *out, int cap) {
 
 int launch_syn_cols(const SynColsArgs &a, hipStream_t s) {
     switch (a.tb.M) {
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return syn_dispatch<VFI_COL_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, s);
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return syn_dispatch<VFI_COL_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, s);
         VFI_WFFT_SYN_CONFIGS(X)
 #undef X
     }

@@ -5,7 +5,7 @@
 namespace vfi {
 namespace pyrw {
 
-#define VFI_COL_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, true, PITCH, P0, P1, P2, R0, R1, R2, R3>
+#define VFI_COL_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, TEAM, true, PITCH, P0, P1, P2, R0, R1, R2, R3>
 
 namespace {
 template <class C>
@@ -23,7 +23,7 @@ int cols_dispatch(const GenColsArgs &a, bool inverse, hipStream_t s) {
 
 int launch_gen_cols(const GenColsArgs &a, bool inverse, hipStream_t s) {
     switch (a.tb.M) {
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return cols_dispatch<VFI_COL_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, inverse, s);
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return cols_dispatch<VFI_COL_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, inverse, s);
         VFI_WFFT_SYN_CONFIGS(X)
 #undef X
     }

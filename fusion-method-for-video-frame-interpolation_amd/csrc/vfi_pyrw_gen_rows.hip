@@ -4,7 +4,7 @@
 namespace vfi {
 namespace pyrw {
 
-#define VFI_ROW_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, false, PITCH, P0, P1, P2, R0, R1, R2, R3>
+#define VFI_ROW_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, TEAM, false, PITCH, P0, P1, P2, R0, R1, R2, R3>
 
 namespace {
 template <class C, bool BLU>
@@ -31,7 +31,7 @@ int rows_dispatch(const GenRowsArgs &a, int load, int store, bool inverse, hipSt
 
 int launch_gen_rows(const GenRowsArgs &a, int load, int store, bool inverse, hipStream_t s) {
     switch (a.tb.M) {
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return rows_dispatch<VFI_ROW_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, load, store, inverse, s);
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return rows_dispatch<VFI_ROW_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, load, store, inverse, s);
         VFI_WFFT_ROW_CONFIGS(X)
 #undef X
     }

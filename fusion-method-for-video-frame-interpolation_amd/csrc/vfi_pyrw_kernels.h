@@ -115,10 +115,10 @@ __device__ __forceinline__ void transform(float2 (&v)[C::E], int lane, const Lds
 // rows: a batch = L consecutive rows of ONE plane (so every descriptor of a batch is wave-uniform)
 // =====================================================================================================================
 template <class C, bool BLU>
-__global__ __launch_bounds__(kMaxThreads) void rows_polar_kernel(const RowsArgs a) {
+__global__ __launch_bounds__(C::TEAM > 64 ? C::TEAM : kMaxThreads, 2) void rows_polar_kernel(const RowsArgs a) {
     using I = Io<C>;
     extern __shared__ float2 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int lane = threadIdx.x % C::TEAM, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / C::TEAM)), nw = blockDim.x / C::TEAM;   // (wave = index of this lane's team)
     Lds<C, BLU> m(lds, a.tb, wave);
     if (threadIdx.x < kMaxImages) m.ints[threadIdx.x] = a.pm.idx[threadIdx.x];
     __syncthreads();
@@ -201,16 +201,16 @@ __global__ __launch_bounds__(kMaxThreads) void rows_polar_kernel(const RowsArgs 
             float mx = gmax[t];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            if (lane == 0 && t < a.groups && mx > 0.0f) atomicMax(a.amp_max + t, __float_as_uint(mx));
+            if ((threadIdx.x & 63) == 0 && t < a.groups && mx > 0.0f) atomicMax(a.amp_max + t, __float_as_uint(mx));
         }
     }
 }
 
 template <class C, bool BLU>
-__global__ __launch_bounds__(kMaxThreads) void rows_from_polar_kernel(const RowsArgs a) {
+__global__ __launch_bounds__(C::TEAM > 64 ? C::TEAM : kMaxThreads, 2) void rows_from_polar_kernel(const RowsArgs a) {
     using I = Io<C>;
     extern __shared__ float2 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int lane = threadIdx.x % C::TEAM, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / C::TEAM)), nw = blockDim.x / C::TEAM;   // (wave = index of this lane's team)
     Lds<C, BLU> m(lds, a.tb, wave);
     if (threadIdx.x < kMaxImages) m.ints[threadIdx.x] = a.pm.idx[threadIdx.x];
     __syncthreads();
@@ -287,12 +287,11 @@ __global__ __launch_bounds__(kMaxThreads) void rows_from_polar_kernel(const Rows
 // (the bands of one column tile, then the next tile), so the 128-byte lines they share stay in one L2.
 __device__ __forceinline__ int xcd_item(int s, int per) { return (s & 7) * per + (s >> 3); }
 
-// (more than 48 values per lane: one wave per SIMD, which may then use the whole register file)
 template <class C, bool BLU>
-__global__ __launch_bounds__(C::E > 48 ? 256 : kMaxThreads) void ana_cols_kernel(const AnaColsArgs a) {
+__global__ __launch_bounds__(C::TEAM > 64 ? C::TEAM : kMaxThreads, 2) void ana_cols_kernel(const AnaColsArgs a) {
     using I = Io<C>;
     extern __shared__ float2 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int lane = threadIdx.x % C::TEAM, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / C::TEAM)), nw = blockDim.x / C::TEAM;   // (wave = index of this lane's team)
     Lds<C, BLU> m(lds, a.tb, wave);
     __syncthreads();
     const int h = a.h, w = a.w, H = a.H, tilew = nw * C::L, ntile = (w + tilew - 1) / tilew;
@@ -361,6 +360,7 @@ template <class C, bool BLU>
 __global__ __launch_bounds__(256, 2) void syn_cols_kernel(const SynColsArgs a) {
     using I = Io<C>;
     static_assert(C::E * wfft::kWave <= C::XBUF, "the exchange buffer doubles as E x 64 scratch words");
+    static_assert(C::TEAM == wfft::kWave, "the synthesis workgroup is four independent waves, one per band");
     extern __shared__ float2 lds[];
     const int lane = threadIdx.x & 63, band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Lds<C, BLU> m(lds, a.tb, band);
@@ -476,11 +476,16 @@ inline int launch_rows(const A &a, int nbatch, hipStream_t s) {
     static Pick cache[kMaxDevices];
     Pick &p = cache[current_device()];
     if (!p.threads) {
-        const Occupancy o4 = occupancy_of<kernel>(256, Lds<C, BLU>::bytes(4)), o8 = occupancy_of<kernel>(512, Lds<C, BLU>::bytes(8));
-        if (o8.blocks * 8 > o4.blocks * 4) { p.threads = 512; p.blocks = o8.blocks; } else { p.threads = 256; p.blocks = o4.blocks; }
-        p.cus = o4.cus;
+        if (C::TEAM > 64) {      // a team of waves is a workgroup of its own
+            const Occupancy o = occupancy_of<kernel>(C::TEAM, Lds<C, BLU>::bytes(1));
+            p.threads = C::TEAM; p.blocks = o.blocks; p.cus = o.cus;
+        } else {
+            const Occupancy o4 = occupancy_of<kernel>(256, Lds<C, BLU>::bytes(4)), o8 = occupancy_of<kernel>(512, Lds<C, BLU>::bytes(8));
+            if (o8.blocks * 8 > o4.blocks * 4) { p.threads = 512; p.blocks = o8.blocks; } else { p.threads = 256; p.blocks = o4.blocks; }
+            p.cus = o4.cus;
+        }
     }
-    const int nw = p.threads / 64;
+    const int nw = p.threads / C::TEAM;
     int grid = (nbatch + nw - 1) / nw;
     if (grid > p.blocks * p.cus) grid = p.blocks * p.cus;
     const size_t lds = Lds<C, BLU>::bytes(nw);
@@ -494,11 +499,11 @@ inline int launch_cols(const A &a, int w, int items_per_tile, hipStream_t s) {
     static Pick cache[kMaxDevices];
     Pick &p = cache[current_device()];
     if (!p.threads) {
-        p.threads = C::L * 4 >= 16 || C::E > 48 ? 256 : 512;
-        const Occupancy o = occupancy_of<kernel>(p.threads, Lds<C, BLU>::bytes(p.threads / 64));
+        p.threads = C::TEAM > 64 ? C::TEAM : (C::L * 4 >= 16 ? 256 : 512);
+        const Occupancy o = occupancy_of<kernel>(p.threads, Lds<C, BLU>::bytes(p.threads / C::TEAM));
         p.blocks = o.blocks; p.cus = o.cus;
     }
-    const int nw = p.threads / 64, tilew = nw * C::L, ntile = (w + tilew - 1) / tilew;
+    const int nw = p.threads / C::TEAM, tilew = nw * C::L, ntile = (w + tilew - 1) / tilew;
     const int nitem = items_per_tile * ntile, per = (nitem + 7) / 8;
     int grid = 8 * per;
     const int cap = (p.blocks * p.cus) / 8 * 8;

@@ -11,10 +11,10 @@ namespace vfi {
 namespace pyrw {
 
 template <class C, bool BLU, int LOAD, int STORE, bool INV>
-__global__ __launch_bounds__(kMaxThreads) void gen_rows_kernel(const GenRowsArgs a) {
+__global__ __launch_bounds__(C::TEAM > 64 ? C::TEAM : kMaxThreads, 2) void gen_rows_kernel(const GenRowsArgs a) {
     using I = Io<C>;
     extern __shared__ float2 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int lane = threadIdx.x % C::TEAM, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / C::TEAM)), nw = blockDim.x / C::TEAM;   // (wave = index of this lane's team)
     Lds<C, BLU> m(lds, a.tb, wave);
     __syncthreads();
     const int n = a.tb.n, wh = n / 2 + 1, nbatch = (a.rows + C::L - 1) / C::L;
@@ -75,7 +75,7 @@ template <class C, bool BLU, bool INV>
 __global__ __launch_bounds__(kMaxThreads) void gen_cols_kernel(const GenColsArgs a) {
     using I = Io<C>;
     extern __shared__ float2 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int lane = threadIdx.x % C::TEAM, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / C::TEAM)), nw = blockDim.x / C::TEAM;   // (wave = index of this lane's team)
     Lds<C, BLU> m(lds, a.tb, wave);
     __syncthreads();
     const int h = a.tb.n, tilew = nw * C::L, ntile = (a.cols + tilew - 1) / tilew;

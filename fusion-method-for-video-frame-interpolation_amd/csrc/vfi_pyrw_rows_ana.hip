@@ -7,7 +7,7 @@
 namespace vfi {
 namespace pyrw {
 
-#define VFI_ROW_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, false, PITCH, P0, P1, P2, R0, R1, R2, R3>
+#define VFI_ROW_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, TEAM, false, PITCH, P0, P1, P2, R0, R1, R2, R3>
 
 namespace {
 template <class C>
@@ -34,7 +34,7 @@ int rows_engine_length(int n, int bluestein_m) {
     const int m = bluestein_m ? bluestein_m : n;
     if (bluestein_m && (!blu_capable(m) || 2 * n > m)) return 0;
     switch (m) {
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return M;
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return M;
         VFI_WFFT_ROW_CONFIGS(X)
 #undef X
     }
@@ -43,7 +43,7 @@ int rows_engine_length(int n, int bluestein_m) {
 
 int rows_twiddles(int M, float2 *out, int cap) {
     switch (M) {
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return twiddles_of<VFI_ROW_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(out, cap);
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return twiddles_of<VFI_ROW_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3)>(out, cap);
         VFI_WFFT_ROW_CONFIGS(X)
 #undef X
     }
@@ -52,7 +52,7 @@ int rows_twiddles(int M, float2 *out, int cap) {
 
 int launch_rows_polar(const RowsArgs &a, hipStream_t s) {
     switch (a.tb.M) {
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return polar_dispatch<VFI_ROW_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, s);
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return polar_dispatch<VFI_ROW_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, s);
         VFI_WFFT_ROW_CONFIGS(X)
 #undef X
     }

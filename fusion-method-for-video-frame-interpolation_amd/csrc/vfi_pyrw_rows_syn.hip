@@ -5,7 +5,7 @@
 namespace vfi {
 namespace pyrw {
 
-#define VFI_ROW_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, false, PITCH, P0, P1, P2, R0, R1, R2, R3>
+#define VFI_ROW_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) Cfg<M, L, TEAM, false, PITCH, P0, P1, P2, R0, R1, R2, R3>
 
 namespace {
 template <class C>
@@ -21,7 +21,7 @@ int from_polar_dispatch(const RowsArgs &a, hipStream_t s) {
 
 int launch_rows_from_polar(const RowsArgs &a, hipStream_t s) {
     switch (a.tb.M) {
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return from_polar_dispatch<VFI_ROW_CFG(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, s);
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return from_polar_dispatch<VFI_ROW_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, s);
         VFI_WFFT_ROW_CONFIGS(X)
 #undef X
     }

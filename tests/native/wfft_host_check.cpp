@@ -1,5 +1,5 @@
 // Host-side check of the wave-private FFT engine (csrc/vfi_wfft.h): the very same per-lane stage / exchange code the
-// device runs, executed on the CPU by looping over the 64 lanes between the points where the wave's LDS traffic is
+// device runs, executed on the CPU by looping over the lanes of a team between the points where its LDS traffic is
 // ordered, for EVERY configuration of csrc/vfi_wfft_configs.h, against a double-precision O(n^2) DFT -- plain
 // transforms and Bluestein's form (a non-smooth length n on each engine length of the form 2^k / 3*2^k).
 // Also checks that no exchange touches a dword outside the wave's buffer.
@@ -34,20 +34,20 @@ static std::vector<cd> dft(const std::vector<cd> &x) {
 template <class C> struct Sim {
     std::vector<float2> tw;
     std::vector<float> xb;
-    float2 v[kWave][C::E];
+    float2 v[C::TEAM][C::E];
     Sim() : tw(C::TW > 0 ? C::TW : 1), xb(C::XBUF + 64, NAN) {
         for_twiddles<C>([&](int idx, int e) {
             tw[idx] = make_float2((float)std::cos(-2.0 * M_PI * e / C::M), (float)std::sin(-2.0 * M_PI * e / C::M));
         });
         for (auto &lane : v) for (auto &z : lane) z = make_float2(NAN, NAN);
     }
-    template <int S> void run_stage() { for (int lane = 0; lane < kWave; ++lane) stage<C, S>(v[lane], lane, tw.data()); }
+    template <int S> void run_stage() { for (int lane = 0; lane < C::TEAM; ++lane) stage<C, S>(v[lane], lane, tw.data()); }
     template <int SW, int SR> void run_exchange() {
         for (int i = 0; i < 64; ++i) xb[C::XBUF + i] = 12345.0f;                                    // guard words
-        for (int lane = 0; lane < kWave; ++lane) exchange_write<C, SW, 0>(v[lane], lane, xb.data());
-        for (int lane = 0; lane < kWave; ++lane) exchange_read<C, SW, SR, 0>(v[lane], lane, xb.data());
-        for (int lane = 0; lane < kWave; ++lane) exchange_write<C, SW, 1>(v[lane], lane, xb.data());
-        for (int lane = 0; lane < kWave; ++lane) exchange_read<C, SW, SR, 1>(v[lane], lane, xb.data());
+        for (int lane = 0; lane < C::TEAM; ++lane) exchange_write<C, SW, 0>(v[lane], lane, xb.data());
+        for (int lane = 0; lane < C::TEAM; ++lane) exchange_read<C, SW, SR, 0>(v[lane], lane, xb.data());
+        for (int lane = 0; lane < C::TEAM; ++lane) exchange_write<C, SW, 1>(v[lane], lane, xb.data());
+        for (int lane = 0; lane < C::TEAM; ++lane) exchange_read<C, SW, SR, 1>(v[lane], lane, xb.data());
         for (int i = 0; i < 64; ++i) if (xb[C::XBUF + i] != 12345.0f) { std::printf("FAIL buffer overrun M=%d\n", C::M); ++g_fail; break; }
     }
     void forward() {
@@ -59,7 +59,7 @@ template <class C> struct Sim {
     // line l, position pos of the first-stage input / last-stage output distribution
     void put_inputs(const std::vector<std::vector<cd>> &x) {
         using I = Io<C>;
-        for (int lane = 0; lane < kWave; ++lane)
+        for (int lane = 0; lane < C::TEAM; ++lane)
             for (int q = 0; q < I::Q0; ++q) {
                 int l, i; bool ok;
                 lane_index<C, 0>(lane, q, l, i, ok);
@@ -72,7 +72,7 @@ template <class C> struct Sim {
     std::vector<std::vector<cd>> get_outputs() {
         using I = Io<C>;
         std::vector<std::vector<cd>> y(C::L, std::vector<cd>(C::M, cd(NAN, NAN)));
-        for (int lane = 0; lane < kWave; ++lane)
+        for (int lane = 0; lane < C::TEAM; ++lane)
             for (int q = 0; q < I::QL; ++q) {
                 int l, k; bool ok;
                 lane_index<C, I::SL>(lane, q, l, k, ok);
@@ -100,7 +100,7 @@ template <class C> static void check_plain(const char *mode) {
     for (int l = 0; l < C::L; l += (C::L > 4 ? C::L / 4 : 1)) worst = std::max(worst, rel_err(y[l], dft(x[l]), C::M));
     const bool ok = worst < 2e-6;
     if (!ok) ++g_fail;
-    std::printf("%s %s M=%4d L=%2d E=%2d stages %d: rel.err %.2e\n", ok ? "ok  " : "FAIL", mode, C::M, C::L, C::E, C::NS, worst);
+    std::printf("%s %s M=%4d L=%2d team %3d E=%2d stages %d: rel.err %.2e\n", ok ? "ok  " : "FAIL", mode, C::M, C::L, C::TEAM, C::E, C::NS, worst);
 }
 
 // Bluestein: DFT of length n (any n with 2n-1 <= M) through two engine transforms, as the device kernels do it
@@ -124,7 +124,7 @@ template <class C> static void check_bluestein(const char *mode, int n) {
         }
     sim->put_inputs(a);
     sim->forward();
-    for (int lane = 0; lane < kWave; ++lane)
+    for (int lane = 0; lane < C::TEAM; ++lane)
         for (int q = 0; q < I::QL; ++q) {
             int l, k; bool ok;
             lane_index<C, I::SL>(lane, q, l, k, ok);
@@ -158,10 +158,10 @@ template <class C> static void check(const char *mode) {
 
 int main() {
     srand48(1);
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) check<Cfg<M, L, false, PITCH, P0, P1, P2, R0, R1, R2, R3>>("rows");
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) check<Cfg<M, L, TEAM, false, PITCH, P0, P1, P2, R0, R1, R2, R3>>("rows");
     VFI_WFFT_ROW_CONFIGS(X)
 #undef X
-#define X(M, L, PITCH, P0, P1, P2, R0, R1, R2, R3) check<Cfg<M, L, true, PITCH, P0, P1, P2, R0, R1, R2, R3>>("cols");
+#define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) check<Cfg<M, L, TEAM, true, PITCH, P0, P1, P2, R0, R1, R2, R3>>("cols");
     VFI_WFFT_COL_CONFIGS(X)
     VFI_WFFT_SYN_CONFIGS(X)
 #undef X

@@ -39,28 +39,28 @@ def sequences(m, max_stages=4):
 
 
 class Geometry:
-    def __init__(self, m, lines, cols, radices):
-        self.m, self.lines, self.cols, self.r = m, lines, cols, tuple(radices)
+    def __init__(self, m, lines, cols, radices, team=WAVE):
+        self.m, self.lines, self.cols, self.r, self.team = m, lines, cols, tuple(radices), team
         self.ns = len(radices)
         self.p = [int(np.prod(radices[:s])) for s in range(self.ns)]
         self.t = [m // r for r in radices]
         self.nb = [lines * t for t in self.t]
-        self.q = [(nb + WAVE - 1) // WAVE for nb in self.nb]
+        self.q = [(nb + team - 1) // team for nb in self.nb]
         self.e = max(q * r for q, r in zip(self.q, self.r))
         self.work = sum(q * r for q, r in zip(self.q, self.r))
 
     def lane_index(self, s, lane, q):
         """-> (line, butterfly index i, valid)"""
-        idx = lane + WAVE * q
+        idx = lane + self.team * q
         if self.cols:
             return idx % self.lines, idx // self.lines, idx < self.nb[s]
         return idx // self.t[s], idx % self.t[s], idx < self.nb[s]
 
 
-def choose_radices(m, lines, cols, want_symmetric):
+def choose_radices(m, lines, cols, want_symmetric, team=WAVE):
     best = None
     for seq in sequences(m):
-        g = Geometry(m, lines, cols, seq)
+        g = Geometry(m, lines, cols, seq, team)
         sym = 0 if (not want_symmetric or seq[0] == seq[-1]) else 1
         # a stage-0 radix that is odd needs no pad word; prefer fewer stages, then fewer registers, then less padded work
         key = (g.ns, g.e, sym, g.work, tuple(-r for r in seq))
@@ -82,7 +82,7 @@ def exchange_addresses(g, s, pads, pitch):
     for q in range(g.q[s]):
         for rr in range(r):
             a = []
-            for lane in range(WAVE):
+            for lane in range(g.team):
                 l, i, ok = g.lane_index(s, lane, q)
                 a.append(l * pitch + phys((i // p) * block + (i % p) + rr * p, block, pads[s]) if ok else None)
             writes.append(a)
@@ -90,7 +90,7 @@ def exchange_addresses(g, s, pads, pitch):
     for q in range(g.q[s + 1]):
         for rr in range(r2):
             a = []
-            for lane in range(WAVE):
+            for lane in range(g.team):
                 l, i, ok = g.lane_index(s + 1, lane, q)
                 a.append(l * pitch + phys(i + rr * t2, block, pads[s]) if ok else None)
             reads.append(a)
@@ -100,7 +100,7 @@ def exchange_addresses(g, s, pads, pitch):
 def conflict_cycles(instrs):
     cyc = 0
     for a in instrs:
-        for half in (a[:32], a[32:]):
+        for half in [a[k:k + 32] for k in range(0, len(a), 32)]:
             banks = {}
             for x in half:
                 if x is not None:
@@ -150,7 +150,7 @@ def simulate(g, pads, pitch, rng):
     """The engine's data flow in numpy (complex128): returns max |error| against numpy.fft."""
     x = rng.standard_normal((g.lines, g.m)) + 1j * rng.standard_normal((g.lines, g.m))
     v = {}
-    for lane in range(WAVE):
+    for lane in range(g.team):
         for q in range(g.q[0]):
             l, i, ok = g.lane_index(0, lane, q)
             for rr in range(g.r[0]):
@@ -158,7 +158,7 @@ def simulate(g, pads, pitch, rng):
     for s in range(g.ns):
         r, p, t = g.r[s], g.p[s], g.t[s]
         out = {}
-        for lane in range(WAVE):
+        for lane in range(g.team):
             for q in range(g.q[s]):
                 l, i, ok = g.lane_index(s, lane, q)
                 k = i % p
@@ -168,7 +168,7 @@ def simulate(g, pads, pitch, rng):
                     out[(lane, q, rr)] = y[rr]
         if s == g.ns - 1:
             res = np.zeros((g.lines, g.m), complex)
-            for lane in range(WAVE):
+            for lane in range(g.team):
                 for q in range(g.q[s]):
                     l, i, ok = g.lane_index(s, lane, q)
                     if ok:
@@ -177,7 +177,7 @@ def simulate(g, pads, pitch, rng):
             return float(np.abs(res - np.fft.fft(x, axis=1)).max())
         buf = {}
         block = p * r
-        for lane in range(WAVE):
+        for lane in range(g.team):
             for q in range(g.q[s]):
                 l, i, ok = g.lane_index(s, lane, q)
                 if ok:
@@ -187,7 +187,7 @@ def simulate(g, pads, pitch, rng):
                         buf[a] = out[(lane, q, rr)]
         v = {}
         r2, t2 = g.r[s + 1], g.t[s + 1]
-        for lane in range(WAVE):
+        for lane in range(g.team):
             for q in range(g.q[s + 1]):
                 l, i, ok = g.lane_index(s + 1, lane, q)
                 for rr in range(r2):
@@ -195,17 +195,27 @@ def simulate(g, pads, pitch, rng):
     raise AssertionError
 
 
-def lines_for(m, cols, cap_e=None):
-    """Lines one wave owns.  Row mode: L * M <= 2048 (<= 32 complex values per lane; the longest lengths take one row).
-    Column mode: as many adjacent columns (<= 16, i.e. up to 128-byte row segments) as keep the values per lane <= cap_e:
-    72 for the analysis columns (144 data registers: one wave per SIMD with the whole 512-register file, 4 columns =
-    32-byte row segments for the 1080-row level), 48 for the synthesis columns (two waves per SIMD: their workgroup is
-    the four bands of the same columns and meets at barriers)."""
-    cap = cap_e * 64 if cols else 2048
+def geometry_for(m, kind):
+    """-> (lines one batch owns, lanes of the team that works on a batch).
+    rows: L * M <= 2048 on one wave (<= 32 complex values per lane; 3072 points: 48).  (A team of two waves for the
+          3072-point rows -- 32 values per lane, no spills -- was 2x SLOWER: every team is a workgroup with its own copy of
+          the 36 KB Bluestein tables in LDS, which leaves 2 teams = 4 waves per CU instead of 8 waves sharing one copy.)
+    analysis columns: lengths >= 512 on a team of four waves with as many adjacent columns (<= 16: 128-byte row segments) as
+          keep <= 36 values per lane (1080 rows: 8 columns, 34 per lane -- one wave owning 4 columns needed 72 per lane and
+          the whole register file of a SIMD); shorter ones on one wave, <= 48 per lane.
+    synthesis / plain columns: one wave, <= 48 values per lane (the synthesis workgroup is the four bands of the same
+          columns and meets at its own barriers)."""
+    if kind == "ROW":
+        l = 1
+        while l < 64 and 2 * l * m <= 2048:
+            l *= 2
+        return l, WAVE
+    team = 256 if (kind == "COL" and m >= 512) else WAVE
+    cap = 36 if team > WAVE else 48
     l = 1
-    while l < (16 if cols else 64) and 2 * l * m <= cap:
+    while l < 16 and 2 * l * m <= cap * team:
         l *= 2
-    return l
+    return l, team
 
 
 def blu_capable(m):
@@ -223,19 +233,20 @@ def main():
     rng = np.random.default_rng(0)
     rows = []
     print("// GENERATED by tools/gen_wfft_configs.py -- do not edit; regenerate after changing the length lists there.")
-    print("// Geometry of the wave-private FFT engine (vfi_wfft.h): X(M, L, PITCH, PAD_0, PAD_1, PAD_2, radices...) for the row passes")
+    print("// Geometry of the wave-private FFT engine (vfi_wfft.h): X(M, L, TEAM, PITCH, PAD_0, PAD_1, PAD_2, radices...) for the row passes")
     print("// (ROW), the analysis column pass (COL) and the synthesis column pass (SYN)")
-    print("//   M = engine length, L = lines (rows / adjacent columns) one wave owns, PITCH = dwords between the lines of the")
+    print("//   M = engine length, L = lines (rows / adjacent columns) of one batch, TEAM = lanes that work on a batch (64 = one wave),")
+    print("//   PITCH = dwords between the lines of the")
     print("//   exchange buffer, PAD_s = pad dwords per block of P_(s+1) positions in the exchange after stage s.")
     print("#pragma once")
-    for cols, lengths, name, cap_e in ((False, ROW_LENGTHS, "ROW", None), (True, COL_LENGTHS, "COL", 72), (True, COL_LENGTHS, "SYN", 48)):
+    for cols, lengths, name in ((False, ROW_LENGTHS, "ROW"), (True, COL_LENGTHS, "COL"), (True, COL_LENGTHS, "SYN")):
         entries = []
         for m in lengths:
-            lines = lines_for(m, cols, cap_e)
-            seq = choose_radices(m, lines, cols, blu_capable(m))
-            g = Geometry(m, lines, cols, seq)
+            lines, team = geometry_for(m, name)
+            seq = choose_radices(m, lines, cols, blu_capable(m), team)
+            g = Geometry(m, lines, cols, seq, team)
             pads, pitch, cyc = choose_layout(g)
-            if cols and lines * pitch < g.e * WAVE:      # (the column kernels also use the buffer as E x 64 scratch words)
+            if name == "SYN" and lines * pitch < g.e * WAVE:      # (the synthesis columns also use the buffer as E x 64 scratch words)
                 pitch += ((g.e * WAVE - lines * pitch + lines - 1) // lines + 31) // 32 * 32
             err = simulate(g, pads, pitch, rng)
             assert err < 1e-9, (m, seq, err)
@@ -243,7 +254,7 @@ def main():
             rows.append((name, m, lines, seq, pads, pitch, g.e, cyc, err))
             pads4 = (list(pads) + [0, 0, 0])[:3]
             rad4 = (list(seq) + [1, 1, 1, 1])[:4]
-            entries.append(f"    X({m}, {lines}, {pitch}, {pads4[0]}, {pads4[1]}, {pads4[2]}, {rad4[0]}, {rad4[1]}, {rad4[2]}, {rad4[3]})"
+            entries.append(f"    X({m}, {lines}, {team}, {pitch}, {pads4[0]}, {pads4[1]}, {pads4[2]}, {rad4[0]}, {rad4[1]}, {rad4[2]}, {rad4[3]})"
                            f"   /* E = {g.e}, stages {g.ns}, simulated LDS cycles per exchange set {cyc} */")
         print(f"#define VFI_WFFT_{name}_CONFIGS(X) \\")
         print(" \\\n".join(entries))
