@@ -810,8 +810,8 @@ int wave_twiddles(vfi_pyr_plan *p, WavePass kind, int M, const float2 **out) {
 }
 // tables of a pass on the wave engine; tb->M == 0 when the engine has no configuration for this length
 int wave_tables(vfi_pyr_plan *p, WavePass kind, const vfi::fft::Plan1D &pl, vfi::pyrw::Tables *tb) {
-    // A/B switch: VFI_PYR_WAVE = bit mask of the passes that may run on the wave engine (1 rows, 2 analysis columns,
-    // 4 synthesis columns and plain column passes; default all, 0 = the generic LDS engine everywhere)
+    // A/B switch: VFI_PYR_WAVE = bit mask of the passes that may run on the wave engine (1 rows, 2 analysis columns and
+    // plain column passes, 4 synthesis columns; default all, 0 = the generic LDS engine everywhere)
     static const int allowed = [] { const char *e = getenv("VFI_PYR_WAVE"); return e ? atoi(e) : 7; }();
     *tb = vfi::pyrw::Tables{};
     const bool off = !((allowed >> (int)kind) & 1);
@@ -855,7 +855,7 @@ int pass_rows(vfi_pyr_plan *p, const vfi::fft::Plan1D &pw, const void *src, void
 int pass_cols(vfi_pyr_plan *p, const vfi::fft::Plan1D &ph, float2 *data, int planes, int cols, int ld, bool inverse, hipStream_t s) {
     using namespace vfi::fft;
     vfi::pyrw::Tables tb;
-    int rc = wave_tables(p, kWaveSynCols, ph, &tb);
+    int rc = wave_tables(p, kWaveAnaCols, ph, &tb);      // (the plain column pass runs with the analysis column geometry)
     if (rc) return rc;
     if (tb.M) {
         vfi::pyrw::GenColsArgs a{tb, data, planes, cols, ld, 1.0f};

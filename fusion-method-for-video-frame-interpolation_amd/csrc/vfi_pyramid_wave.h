@@ -68,7 +68,7 @@ struct GenRowsArgs {
     float scale;
 };
 struct GenColsArgs {
-    Tables tb;                    // tb.n = column length (rows of a plane); tables of the SYNTHESIS column configurations
+    Tables tb;                    // tb.n = column length (rows of a plane); tables of the ANALYSIS column configurations
     float2 *data;                 // [planes][n][ld], transformed in place
     int planes, cols, ld;
     float scale;

@@ -1,5 +1,5 @@
-// Plain column passes on the wave-private FFT engine: gen_cols_kernel (vfi_pyrw_passes.h) for every synthesis column
-// configuration (two waves per SIMD).
+// Plain column passes on the wave-private FFT engine: gen_cols_kernel (vfi_pyrw_passes.h) for every analysis column
+// configuration (the long lengths on a team of waves: 8 columns = 64-byte row segments for 1080 rows).
 #include "vfi_pyrw_passes.h"
 
 namespace vfi {
@@ -24,7 +24,7 @@ int cols_dispatch(const GenColsArgs &a, bool inverse, hipStream_t s) {
 int launch_gen_cols(const GenColsArgs &a, bool inverse, hipStream_t s) {
     switch (a.tb.M) {
 #define X(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3) case M: return cols_dispatch<VFI_COL_CFG(M, L, TEAM, PITCH, P0, P1, P2, R0, R1, R2, R3)>(a, inverse, s);
-        VFI_WFFT_SYN_CONFIGS(X)
+        VFI_WFFT_COL_CONFIGS(X)
 #undef X
     }
     return vfi::fail(VFI_ERR_UNSUPPORTED, "fft columns: no engine configuration for length %d", a.tb.M);

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(C::TEAM > 64 ? C::TEAM : kMaxThreads, 2) void gen_r
 }
 
 template <class C, bool BLU, bool INV>
-__global__ __launch_bounds__(kMaxThreads) void gen_cols_kernel(const GenColsArgs a) {
+__global__ __launch_bounds__(C::TEAM > 64 ? C::TEAM : kMaxThreads, 2) void gen_cols_kernel(const GenColsArgs a) {
     using I = Io<C>;
     extern __shared__ float2 lds[];
     const int lane = threadIdx.x % C::TEAM, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / C::TEAM)), nw = blockDim.x / C::TEAM;   // (wave = index of this lane's team)
