@@ -31,6 +31,32 @@ def _models(device, weights):
     return FusionInterpolator(adacof, fusion, weights["phasenet"], device)
 
 
+def _assert_stage_parity(got, ref, f1_true, label):
+    """Every stage output of the fused frame against the oracle pipeline: >= 60 dB on [0,1] images.
+
+    `ada_uncertainty` is checked in two parts, because the reference's own formula for it (|phase| and |amplitude|
+    differences of the six coarsest levels -> reconstruction -> x150 -> distance from a 50x50 median,
+    src/fusion_net/interpolate_twoframe.py:217-225) amplifies a perturbation of its INPUT images by ~50 dB: the oracle fed
+    two `phase_pred` images that agree to 125 dB returns maps that agree to only ~73 dB
+    (tests/test_oracle_conditioning.py measures this on the CPU).  So (a) the stage itself -- the oracle's
+    uncertainty_maps() applied to the product's OWN ada_pred / phase_pred -- must reproduce the product's map at >= 60 dB
+    (it does at ~99 dB), and (b) end to end, where the two pipelines' phase_pred differ by fp32 rounding (110-127 dB), the
+    map must stay >= 40 dB.  Everything downstream of it (`final`) is held to the 60 dB bar again."""
+    from oracle import layout_cpu, pyramid_cpu, uncertainty_cpu
+    report = {k: _psnr(got[k].cpu(), ref[k]) for k in ref}
+    h, w = ref["final"].shape[-2:]
+    opyr = pyramid_cpu.Pyramid(layout_cpu.calc_pyr_height(h, w), 4, np.sqrt(2))
+    pu, au = uncertainty_cpu.uncertainty_maps(opyr, got["ada_pred"][0].cpu(), got["phase_pred"][0].cpu())
+    report["ada_uncertainty | own inputs"] = _psnr(got["ada_uncertainty"].cpu(), au)
+    report["phase_uncertainty | own inputs"] = _psnr(got["phase_uncertainty"].cpu(), pu)
+    print(label, report)
+    for k, v in report.items():
+        assert v >= (40.0 if k == "ada_uncertainty" else 60.0), (k, report)
+    # |PSNR(HIP, GT) - PSNR(CPU, GT)| <= 0.01 dB on the analytic middle frame
+    assert abs(_psnr(got["final"].cpu()[0], f1_true) - _psnr(ref["final"][0], f1_true)) <= 0.01
+    return report
+
+
 @pytest.mark.parametrize("h,w", [(128, 160), (96, 96)])
 def test_fused_frame_matches_oracle(h, w, device):
     weights = pipeline_cpu.seeded_weights(0)
@@ -39,15 +65,7 @@ def test_fused_frame_matches_oracle(h, w, device):
     run = _models(device, weights)
     got = run(f0.to(device), f2.to(device), output_baseline=True)
     torch.cuda.synchronize()
-    report = {k: _psnr(got[k].cpu(), ref[k]) for k in ref}
-    print(report)
-    # stage outputs: >= 60 dB on [0,1] images; the pyramid-only reconstruction far higher
-    for k in ("ada_pred", "phase_pred", "base", "baseline", "final"):
-        assert report[k] >= 60.0, (k, report)
-    for k in ("flow_var_map", "phase_uncertainty", "ada_uncertainty"):
-        assert report[k] >= 60.0, (k, report)
-    # |PSNR(HIP, GT) - PSNR(CPU, GT)| <= 0.01 dB on the analytic middle frame
-    assert abs(_psnr(got["final"].cpu()[0], f1_true) - _psnr(ref["final"][0], f1_true)) <= 0.01
+    _assert_stage_parity(got, ref, f1_true, f"configs[0] fused frame {h}x{w} vs oracle:")
 
 
 def test_runner_reuses_state_and_is_deterministic(device):
@@ -205,11 +223,7 @@ def test_fused_frame_720p_matches_oracle(pair_720, device):
     run = _models(device, weights)
     got = run(f0.to(device), f2.to(device), output_baseline=True)
     torch.cuda.synchronize()
-    report = {k: _psnr(got[k].cpu(), ref[k]) for k in ref}
-    print("configs[3] fused frame 720p vs oracle:", report)
-    for k, v in report.items():
-        assert v >= 60.0, (k, report)
-    assert abs(_psnr(got["final"].cpu()[0], f1_true) - _psnr(ref["final"][0], f1_true)) <= 0.01
+    _assert_stage_parity(got, ref, f1_true, "configs[3] fused frame 720p vs oracle:")
 
 
 def test_fused_frame_1080p_matches_oracle(device):
@@ -225,11 +239,7 @@ def test_fused_frame_1080p_matches_oracle(device):
     run = _models(device, weights)
     got = run(f0.to(device), f2.to(device), output_baseline=True)
     torch.cuda.synchronize()
-    report = {k: _psnr(got[k].cpu(), ref[k]) for k in ref}
-    print("configs[3] fused frame 1080p vs oracle:", report)
-    for k, v in report.items():
-        assert v >= 60.0, (k, report)
-    assert abs(_psnr(got["final"].cpu()[0], f1_true) - _psnr(ref["final"][0], f1_true)) <= 0.01
+    _assert_stage_parity(got, ref, f1_true, "configs[3] fused frame 1080p vs oracle:")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -4,7 +4,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "fusion-method-for-video-frame-interpol
 from oracle import pyramid_cpu, synth, layout_cpu
 from vfi_amd.train.pyramid import Pyramid
 dev = torch.device("cuda:0")
-for (h, w) in [(128, 160), (96, 96), (64, 96)]:
+SIZES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(128, 160), (96, 96), (64, 96)]
+for (h, w) in SIZES:
     f0, _, f2 = synth.translating_pair(7, h, w)
     img = torch.from_numpy(np.concatenate([f0, f2], 0))
     height = layout_cpu.calc_pyr_height(h, w)
