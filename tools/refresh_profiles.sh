@@ -28,6 +28,18 @@ rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pyrprof -o pp -- pyth
 python3 tools/pyr_kernel_table.py "$(find gpurun_out/pyrprof -name '*kernel_trace.csv' | head -1)" 40 > gpurun_out/${R}_pyramid_kernel_table.txt
 find gpurun_out/pyrprof -name "*kernel_trace.csv" -delete
 python3 tools/pyramid_bench.py > gpurun_out/${R}_pyramid_bench.txt 2>> gpurun_out/refresh.log
+log "pyramid PMC passes (counters only, one pass per set)"
+PA="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY"
+PB="SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY"
+export ITERS=2
+rocprofv3 --pmc $PA --output-format csv -d gpurun_out/pyrpmc_a -o p -- python3 tools/pyramid_bench.py > /dev/null 2>> gpurun_out/refresh.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pyrpmc_f -o p -- python3 tools/pyramid_bench.py > /dev/null 2>> gpurun_out/refresh.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pyrpmc_w -o p -- python3 tools/pyramid_bench.py > /dev/null 2>> gpurun_out/refresh.log
+rocprofv3 --pmc $PB --output-format csv -d gpurun_out/pyrpmc_b -o p -- python3 tools/pyramid_bench.py > /dev/null 2>> gpurun_out/refresh.log
+unset ITERS
+python3 tools/pyr_pmc_table.py gpurun_out/pyrpmc_a gpurun_out/pyrpmc_f gpurun_out/pyrpmc_w > gpurun_out/${R}_pyramid_pmc_a.txt
+python3 tools/pyr_pmc_table.py gpurun_out/pyrpmc_b > gpurun_out/${R}_pyramid_pmc_b.txt
+find gpurun_out/pyrpmc_a gpurun_out/pyrpmc_f gpurun_out/pyrpmc_w gpurun_out/pyrpmc_b -name "*counter_collection.csv" -delete
 log "host enqueue time per frame (eager) and two ranks on one GPU over RCCL"
 python3 tools/probes/enqueue_time.py > gpurun_out/${R}_enqueue_time.txt 2>> gpurun_out/refresh.log
 # (RCCL refuses two ranks on one device -- "Duplicate GPU detected" -- so the one-GPU rehearsal of the N = 2 path runs on gloo)
