@@ -47,21 +47,88 @@ struct Plan1D {                      // plain data, passed to kernels by value
 
 #define VFI_HD __host__ __device__ __forceinline__
 
-VFI_HD float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-VFI_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-VFI_HD float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// ---- complex arithmetic on PACKED f32 instructions ------------------------------------------------------------------------
+// The transforms are vector-issue bound, and v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on a
+// (re, im) register pair at the price of one instruction: a complex add is one instruction, a complex product two, an
+// add of a value turned by -+i one (the turn is an operand modifier).  hipcc packs plain `a + b` on two-element vectors by
+// itself but does not fold a swap-and-negate into op_sel / neg, so those forms are written out (tools/probes/pk_complex.hip
+// checks them against scalar arithmetic on the GPU); the host build (tests/native/*) takes the scalar expressions.
+typedef float cpk __attribute__((ext_vector_type(2)));
+VFI_HD cpk pk(float2 a) { return cpk{a.x, a.y}; }
+VFI_HD float2 unpk(cpk a) { return make_float2(a.x, a.y); }
+VFI_HD float2 cadd(float2 a, float2 b) { return unpk(pk(a) + pk(b)); }
+VFI_HD float2 csub(float2 a, float2 b) { return unpk(pk(a) - pk(b)); }
 VFI_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+VFI_HD float2 cscale(float2 a, float k) { return unpk(pk(a) * k); }
+VFI_HD float2 cfma(float2 a, float k, float2 b) { return unpk(pk(a) * k + pk(b)); }      // a * k + b, k real
+// a * b
+VFI_HD float2 cmul(float2 a, float2 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const cpk A = pk(a), B = pk(b);
+    cpk t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(A), "v"(B));                // (-a.y b.y, a.y b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(A), "v"(B), "v"(t));             // + (a.x b.x, a.x b.y)
+    return unpk(r);
+#else
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
+}
+// a * conj(b)
+VFI_HD float2 cmulc(float2 a, float2 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const cpk A = pk(a), B = pk(b);
+    cpk t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(A), "v"(B));                             // (a.y b.y, a.y b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(A), "v"(B), "v"(t));   // + (a.x b.x, -a.x b.y)
+    return unpk(r);
+#else
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+#endif
+}
+// conj(a * b)
+VFI_HD float2 cmul_cj(float2 a, float2 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const cpk A = pk(a), B = pk(b);
+    cpk t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(A), "v"(B));   // (-a.y b.y, -a.y b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(A), "v"(B), "v"(t));   // + (a.x b.x, -a.x b.y)
+    return unpk(r);
+#else
+    return make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));
+#endif
+}
+// a * (kr -+ i ki) with compile-time constants (forward: kr - i ki = the conjugate of exp(+i..) tables; inverse: kr + i ki);
+// the constant pair sits in two SGPRs
+template <bool INV> VFI_HD float2 cmul_k(float2 a, float kr, float ki) {
+    const float kim = INV ? ki : -ki;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const cpk A = pk(a), K = {kr, kim};
+    cpk t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(A), "s"(K));                                          // (a.x kr, a.y kr)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(A), "s"(K), "v"(t));   // + (-a.y ki, a.x ki)
+    return unpk(r);
+#else
+    return make_float2(a.x * kr - a.y * kim, a.y * kr + a.x * kim);
+#endif
+}
 // multiply by -i (forward transform) or +i (inverse)
 template <bool INV> VFI_HD float2 rot(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
-// multiply by exp(-+ i pi/4) * sqrt(2)/... : W8^1 (forward: (1 - i)/sqrt2, inverse: (1 + i)/sqrt2)
-template <bool INV> VFI_HD float2 w8_1(float2 a) {
-    constexpr float h = 0.70710678118654752440f;
-    return INV ? make_float2(h * (a.x - a.y), h * (a.x + a.y)) : make_float2(h * (a.x + a.y), h * (a.y - a.x));
+// t + rot(v), t - rot(v): one instruction each
+template <bool INV> VFI_HD float2 add_rot(float2 t, float2 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const cpk T = pk(t), V = pk(v);
+    cpk r;
+    if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(T), "v"(V));       // (t.x - v.y, t.y + v.x)
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(T), "v"(V));           // (t.x + v.y, t.y - v.x)
+    return unpk(r);
+#else
+    return cadd(t, rot<INV>(v));
+#endif
 }
-template <bool INV> VFI_HD float2 w8_3(float2 a) {   // W8^3 (forward: (-1 - i)/sqrt2, inverse: (-1 + i)/sqrt2)
-    constexpr float h = 0.70710678118654752440f;
-    return INV ? make_float2(-h * (a.x + a.y), h * (a.x - a.y)) : make_float2(h * (a.y - a.x), -h * (a.x + a.y));
-}
+template <bool INV> VFI_HD float2 sub_rot(float2 t, float2 v) { return add_rot<!INV>(t, v); }
+// W8^1 (forward: (1 - i)/sqrt2, inverse: (1 + i)/sqrt2) and W8^3 (forward: (-1 - i)/sqrt2, inverse: (-1 + i)/sqrt2)
+template <bool INV> VFI_HD float2 w8_1(float2 a) { return cscale(add_rot<INV>(a, a), 0.70710678118654752440f); }
+template <bool INV> VFI_HD float2 w8_3(float2 a) { return cscale(sub_rot<INV>(a, a), -0.70710678118654752440f); }
 
 template <int R, bool INV> struct Dft;
 template <bool INV> struct Dft<2, INV> {
@@ -73,15 +140,15 @@ template <bool INV> struct Dft<2, INV> {
 template <bool INV> struct Dft<3, INV> {
     static VFI_HD void run(float2 *v) {
         const float2 a = v[0], s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
-        const float2 m = make_float2(a.x - 0.5f * s.x, a.y - 0.5f * s.y);
-        const float2 q = rot<INV>(make_float2(0.86602540378443864676f * d.x, 0.86602540378443864676f * d.y));
-        v[0] = cadd(a, s); v[1] = cadd(m, q); v[2] = csub(m, q);
+        const float2 m = cfma(s, -0.5f, a);
+        const float2 e = cscale(d, 0.86602540378443864676f);
+        v[0] = cadd(a, s); v[1] = add_rot<INV>(m, e); v[2] = sub_rot<INV>(m, e);
     }
 };
 template <bool INV> struct Dft<4, INV> {
     static VFI_HD void run(float2 *v) {
-        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = rot<INV>(csub(v[1], v[3]));
-        v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+        v[0] = cadd(t0, t2); v[1] = add_rot<INV>(t1, d); v[2] = csub(t0, t2); v[3] = sub_rot<INV>(t1, d);
     }
 };
 template <bool INV> struct Dft<5, INV> {
@@ -89,13 +156,13 @@ template <bool INV> struct Dft<5, INV> {
         constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;   // cos(2pi/5), cos(4pi/5)
         constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;    // sin(2pi/5), sin(4pi/5)
         const float2 a = v[0], t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-        const float2 m1 = make_float2(a.x + c1 * t1.x + c2 * t2.x, a.y + c1 * t1.y + c2 * t2.y);
-        const float2 m2 = make_float2(a.x + c2 * t1.x + c1 * t2.x, a.y + c2 * t1.y + c1 * t2.y);
-        const float2 n1 = rot<INV>(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
-        const float2 n2 = rot<INV>(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
-        v[0] = make_float2(a.x + t1.x + t2.x, a.y + t1.y + t2.y);
-        v[1] = cadd(m1, n1); v[4] = csub(m1, n1);
-        v[2] = cadd(m2, n2); v[3] = csub(m2, n2);
+        const float2 m1 = cfma(t2, c2, cfma(t1, c1, a));
+        const float2 m2 = cfma(t2, c1, cfma(t1, c2, a));
+        const float2 e1 = cfma(t4, s2, cscale(t3, s1));
+        const float2 e2 = cfma(t4, -s1, cscale(t3, s2));
+        v[0] = cadd(cadd(a, t1), t2);
+        v[1] = add_rot<INV>(m1, e1); v[4] = sub_rot<INV>(m1, e1);
+        v[2] = add_rot<INV>(m2, e2); v[3] = sub_rot<INV>(m2, e2);
     }
 };
 template <bool INV> struct Dft<8, INV> {
@@ -103,9 +170,11 @@ template <bool INV> struct Dft<8, INV> {
         float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
         Dft<4, INV>::run(e);
         Dft<4, INV>::run(o);
-        o[1] = w8_1<INV>(o[1]); o[2] = rot<INV>(o[2]); o[3] = w8_3<INV>(o[3]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+        o[1] = w8_1<INV>(o[1]); o[3] = w8_3<INV>(o[3]);
+        v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], o[1]); v[5] = csub(e[1], o[1]);
+        v[2] = add_rot<INV>(e[2], o[2]); v[6] = sub_rot<INV>(e[2], o[2]);      // (o[2] turned by -+i)
+        v[3] = cadd(e[3], o[3]); v[7] = csub(e[3], o[3]);
     }
 };
 template <bool INV> struct Dft<16, INV> {
@@ -119,26 +188,26 @@ template <bool INV> struct Dft<16, INV> {
 #pragma unroll
             for (int q = 0; q < 4; ++q) t[c][q] = col[q];
         }
-        // W16^e, e = c*q: cos/sin(2 pi e / 16)
+        // W16^e, e = c*q: cos/sin(2 pi e / 16); a * (cr - i si) forward, a * (cr + i si) inverse
         constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
-        auto tw = [](float2 a, float cr, float si) {   // a * (cr - i si) forward, a * (cr + i si) inverse
-            return INV ? make_float2(a.x * cr - a.y * si, a.x * si + a.y * cr) : make_float2(a.x * cr + a.y * si, a.y * cr - a.x * si);
-        };
-        t[1][1] = tw(t[1][1], c1, s1);            // e = 1
-        t[1][2] = tw(t[1][2], h, h);              // e = 2
-        t[1][3] = tw(t[1][3], s1, c1);            // e = 3
-        t[2][1] = tw(t[2][1], h, h);              // e = 2
-        t[2][2] = rot<INV>(t[2][2]);              // e = 4
-        t[2][3] = tw(t[2][3], -h, h);             // e = 6
-        t[3][1] = tw(t[3][1], s1, c1);            // e = 3
-        t[3][2] = tw(t[3][2], -h, h);             // e = 6
-        t[3][3] = tw(t[3][3], -c1, -s1);          // e = 9
+        t[1][1] = cmul_k<INV>(t[1][1], c1, s1);            // e = 1
+        t[1][2] = w8_1<INV>(t[1][2]);                      // e = 2
+        t[1][3] = cmul_k<INV>(t[1][3], s1, c1);            // e = 3
+        t[2][1] = w8_1<INV>(t[2][1]);                      // e = 2
+        t[2][3] = w8_3<INV>(t[2][3]);                      // e = 6
+        t[3][1] = cmul_k<INV>(t[3][1], s1, c1);            // e = 3
+        t[3][2] = w8_3<INV>(t[3][2]);                      // e = 6
+        t[3][3] = cmul_k<INV>(t[3][3], -c1, -s1);          // e = 9
+        (void)h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float2 row[4] = {t[0][q], t[1][q], t[2][q], t[3][q]};
-            Dft<4, INV>::run(row);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) v[q + 4 * s] = row[s];
+            // row q: {t[0][q], t[1][q], t[2][q] (turned by -+i for q = 2: e = 4), t[3][q]} through a radix-4 butterfly
+            const float2 x0 = t[0][q], x1 = t[1][q], x2 = t[2][q], x3 = t[3][q];
+            float2 t0, t1;
+            if (q == 2) { t0 = add_rot<INV>(x0, x2); t1 = sub_rot<INV>(x0, x2); }
+            else { t0 = cadd(x0, x2); t1 = csub(x0, x2); }
+            const float2 t2 = cadd(x1, x3), d = csub(x1, x3);
+            v[q] = cadd(t0, t2); v[q + 4] = add_rot<INV>(t1, d); v[q + 8] = csub(t0, t2); v[q + 12] = sub_rot<INV>(t1, d);
         }
     }
 };
@@ -204,7 +273,7 @@ template <int R1, int R2, bool INV> struct DftComposite {
             for (int q = 0; q < R2; ++q) {
                 if (c * q == 0) { t[c][q] = col[q]; continue; }
                 const float2 w = Cis<R>::at((c * q) % R);      // forward: exp(-i..) = conj
-                t[c][q] = cmul(col[q], INV ? w : cconj(w));
+                t[c][q] = cmul_k<INV>(col[q], w.x, w.y);
             }
         }
 #pragma unroll
@@ -306,7 +375,7 @@ VFI_HD void stage_gather(StageRegs<R> &s, const Team tm, const float2 *buf, int 
         if (tm.nthr * q < total) {
             if (MULB) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) s.v[q][r] = cconj(cmul(s.v[q][r], bf[MULB ? q : 0][MULB ? r : 0]));
+                for (int r = 0; r < R; ++r) s.v[q][r] = cmul_cj(s.v[q][r], bf[MULB ? q : 0][MULB ? r : 0]);
             }
             if (p > 1) {
                 float2 wr[R > 2 ? R : 3];
@@ -354,7 +423,7 @@ template <bool INV> VFI_HD float2 load_value(float2 x, float2 chirp, bool bluest
     return bluestein ? cmul(x, chirp) : x;
 }
 template <bool INV> VFI_HD float2 store_value(float2 b, float2 chirp, bool bluestein) {
-    if (bluestein) b = cmul(chirp, cconj(b));
+    if (bluestein) b = cmulc(chirp, b);
     return INV ? cconj(b) : b;
 }
 
