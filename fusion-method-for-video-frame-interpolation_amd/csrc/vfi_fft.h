@@ -65,9 +65,10 @@ VFI_HD float2 cfma(float2 a, float k, float2 b) { return unpk(pk(a) * k + pk(b))
 VFI_HD float2 cmul(float2 a, float2 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const cpk A = pk(a), B = pk(b);
-    cpk t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(A), "v"(B));                // (-a.y b.y, a.y b.x)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(A), "v"(B), "v"(t));             // + (a.x b.x, a.x b.y)
+    cpk r;      // (-a.y b.y, a.y b.x) + (a.x b.x, a.x b.y); one statement: the compiler pads every asm statement whose result the
+                // next instruction reads with a wait state, the pair itself needs none
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=&v"(r) : "v"(A), "v"(B));
     return unpk(r);
 #else
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -77,9 +78,9 @@ VFI_HD float2 cmul(float2 a, float2 b) {
 VFI_HD float2 cmulc(float2 a, float2 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const cpk A = pk(a), B = pk(b);
-    cpk t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(A), "v"(B));                             // (a.y b.y, a.y b.x)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(A), "v"(B), "v"(t));   // + (a.x b.x, -a.x b.y)
+    cpk r;      // (a.y b.y, a.y b.x) + (a.x b.x, -a.x b.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=&v"(r) : "v"(A), "v"(B));
     return unpk(r);
 #else
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
@@ -89,9 +90,9 @@ VFI_HD float2 cmulc(float2 a, float2 b) {
 VFI_HD float2 cmul_cj(float2 a, float2 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const cpk A = pk(a), B = pk(b);
-    cpk t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(A), "v"(B));   // (-a.y b.y, -a.y b.x)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(A), "v"(B), "v"(t));   // + (a.x b.x, -a.x b.y)
+    cpk r;      // (-a.y b.y, -a.y b.x) + (a.x b.x, -a.x b.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=&v"(r) : "v"(A), "v"(B));
     return unpk(r);
 #else
     return make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));
@@ -103,9 +104,9 @@ template <bool INV> VFI_HD float2 cmul_k(float2 a, float kr, float ki) {
     const float kim = INV ? ki : -ki;
 #if defined(__HIP_DEVICE_COMPILE__)
     const cpk A = pk(a), K = {kr, kim};
-    cpk t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(A), "s"(K));                                          // (a.x kr, a.y kr)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(A), "s"(K), "v"(t));   // + (-a.y ki, a.x ki)
+    cpk r;      // (a.x kr, a.y kr) + (-a.y ki, a.x ki)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=&v"(r) : "v"(A), "s"(K));
     return unpk(r);
 #else
     return make_float2(a.x * kr - a.y * kim, a.y * kr + a.x * kim);
@@ -127,8 +128,28 @@ template <bool INV> VFI_HD float2 add_rot(float2 t, float2 v) {
 }
 template <bool INV> VFI_HD float2 sub_rot(float2 t, float2 v) { return add_rot<!INV>(t, v); }
 // W8^1 (forward: (1 - i)/sqrt2, inverse: (1 + i)/sqrt2) and W8^3 (forward: (-1 - i)/sqrt2, inverse: (-1 + i)/sqrt2)
-template <bool INV> VFI_HD float2 w8_1(float2 a) { return cscale(add_rot<INV>(a, a), 0.70710678118654752440f); }
-template <bool INV> VFI_HD float2 w8_3(float2 a) { return cscale(sub_rot<INV>(a, a), -0.70710678118654752440f); }
+template <bool INV> VFI_HD float2 w8_1(float2 a) {      // h * (a + rot(a))
+#if defined(__HIP_DEVICE_COMPILE__)
+    const cpk A = pk(a), K = {0.70710678118654752440f, 0.70710678118654752440f};
+    cpk r;
+    if (INV) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(r) : "v"(A), "s"(K));
+    else asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(r) : "v"(A), "s"(K));
+    return unpk(r);
+#else
+    return cscale(add_rot<INV>(a, a), 0.70710678118654752440f);
+#endif
+}
+template <bool INV> VFI_HD float2 w8_3(float2 a) {      // -h * (a - rot(a))
+#if defined(__HIP_DEVICE_COMPILE__)
+    const cpk A = pk(a), K = {-0.70710678118654752440f, -0.70710678118654752440f};
+    cpk r;
+    if (INV) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(r) : "v"(A), "s"(K));
+    else asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(r) : "v"(A), "s"(K));
+    return unpk(r);
+#else
+    return cscale(sub_rot<INV>(a, a), -0.70710678118654752440f);
+#endif
+}
 
 template <int R, bool INV> struct Dft;
 template <bool INV> struct Dft<2, INV> {
