@@ -56,14 +56,22 @@ struct Plan1D {                      // plain data, passed to kernels by value
 typedef float cpk __attribute__((ext_vector_type(2)));
 VFI_HD cpk pk(float2 a) { return cpk{a.x, a.y}; }
 VFI_HD float2 unpk(cpk a) { return make_float2(a.x, a.y); }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VFI_FFT_SCALAR_COMPLEX)
+#define VFI_FFT_PACKED 1
 VFI_HD float2 cadd(float2 a, float2 b) { return unpk(pk(a) + pk(b)); }
 VFI_HD float2 csub(float2 a, float2 b) { return unpk(pk(a) - pk(b)); }
-VFI_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 VFI_HD float2 cscale(float2 a, float k) { return unpk(pk(a) * k); }
 VFI_HD float2 cfma(float2 a, float k, float2 b) { return unpk(pk(a) * k + pk(b)); }      // a * k + b, k real
+#else
+VFI_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+VFI_HD float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+VFI_HD float2 cscale(float2 a, float k) { return make_float2(a.x * k, a.y * k); }
+VFI_HD float2 cfma(float2 a, float k, float2 b) { return make_float2(a.x * k + b.x, a.y * k + b.y); }
+#endif
+VFI_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 // a * b
 VFI_HD float2 cmul(float2 a, float2 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(VFI_FFT_PACKED)
     const cpk A = pk(a), B = pk(b);
     cpk r;      // (-a.y b.y, a.y b.x) + (a.x b.x, a.x b.y); one statement: the compiler pads every asm statement whose result the
                 // next instruction reads with a wait state, the pair itself needs none
@@ -76,7 +84,7 @@ VFI_HD float2 cmul(float2 a, float2 b) {
 }
 // a * conj(b)
 VFI_HD float2 cmulc(float2 a, float2 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(VFI_FFT_PACKED)
     const cpk A = pk(a), B = pk(b);
     cpk r;      // (a.y b.y, a.y b.x) + (a.x b.x, -a.x b.y)
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
@@ -88,7 +96,7 @@ VFI_HD float2 cmulc(float2 a, float2 b) {
 }
 // conj(a * b)
 VFI_HD float2 cmul_cj(float2 a, float2 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(VFI_FFT_PACKED)
     const cpk A = pk(a), B = pk(b);
     cpk r;      // (-a.y b.y, -a.y b.x) + (a.x b.x, -a.x b.y)
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -102,7 +110,7 @@ VFI_HD float2 cmul_cj(float2 a, float2 b) {
 // the constant pair sits in two SGPRs
 template <bool INV> VFI_HD float2 cmul_k(float2 a, float kr, float ki) {
     const float kim = INV ? ki : -ki;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(VFI_FFT_PACKED)
     const cpk A = pk(a), K = {kr, kim};
     cpk r;      // (a.x kr, a.y kr) + (-a.y ki, a.x ki)
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
@@ -116,7 +124,7 @@ template <bool INV> VFI_HD float2 cmul_k(float2 a, float kr, float ki) {
 template <bool INV> VFI_HD float2 rot(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
 // t + rot(v), t - rot(v): one instruction each
 template <bool INV> VFI_HD float2 add_rot(float2 t, float2 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(VFI_FFT_PACKED)
     const cpk T = pk(t), V = pk(v);
     cpk r;
     if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(T), "v"(V));       // (t.x - v.y, t.y + v.x)
@@ -129,7 +137,7 @@ template <bool INV> VFI_HD float2 add_rot(float2 t, float2 v) {
 template <bool INV> VFI_HD float2 sub_rot(float2 t, float2 v) { return add_rot<!INV>(t, v); }
 // W8^1 (forward: (1 - i)/sqrt2, inverse: (1 + i)/sqrt2) and W8^3 (forward: (-1 - i)/sqrt2, inverse: (-1 + i)/sqrt2)
 template <bool INV> VFI_HD float2 w8_1(float2 a) {      // h * (a + rot(a))
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(VFI_FFT_PACKED)
     const cpk A = pk(a), K = {0.70710678118654752440f, 0.70710678118654752440f};
     cpk r;
     if (INV) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(r) : "v"(A), "s"(K));
@@ -140,7 +148,7 @@ template <bool INV> VFI_HD float2 w8_1(float2 a) {      // h * (a + rot(a))
 #endif
 }
 template <bool INV> VFI_HD float2 w8_3(float2 a) {      // -h * (a - rot(a))
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(VFI_FFT_PACKED)
     const cpk A = pk(a), K = {-0.70710678118654752440f, -0.70710678118654752440f};
     cpk r;
     if (INV) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(r) : "v"(A), "s"(K));
