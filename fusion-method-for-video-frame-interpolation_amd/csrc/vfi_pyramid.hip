@@ -394,12 +394,12 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles) {
 // memory operations (vmcnt(0): loads and stores share the counter) in front of every element -- also on the smooth
 // levels, the large ones, that never load a chirp factor.
 template <int NB, bool BLU>
-__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_level_cols_kernel(const LevelColsArgs a) {
+__device__ __forceinline__ void level_cols_body(const LevelColsArgs &a, const int block_x, const int n) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
-    const int h = a.h, w = a.w, H = a.H, m = a.ph.m, tid = threadIdx.x, C = a.tile, n = blockIdx.y;
+    const int h = a.h, w = a.w, H = a.H, m = a.ph.m, tid = threadIdx.x, C = a.tile;
     const int ntiles = (w + C - 1) / C;
-    const int tile = tile_of_block(blockIdx.x, ntiles);
+    const int tile = tile_of_block(block_x, ntiles);
     if (tile >= ntiles) return;
     const int pitch = ((padded_length(m) + 31) & ~31) + (C < 32 ? 32 / C : 1);
     const int v0 = tile * C, lines = w - v0 < C ? w - v0 : C;
@@ -481,6 +481,26 @@ struct RowsPolarArgs {
     int groups;
 };
 
+template <int NB, bool BLU>
+__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_level_cols_kernel(const LevelColsArgs a) {
+    level_cols_body<NB, BLU>(a, blockIdx.x, blockIdx.y);
+}
+// Several SMALL levels in one launch: below ~135 x 240 a level is a handful of workgroups and a launch costs 16-30 us
+// whatever it holds, and the levels of an analysis do not depend on each other.  blockIdx.x runs over the levels' tiles
+// (first[i] = first block of entry i), every entry has its own region of T.
+constexpr int kMaxMulti = 12;
+struct MultiColsArgs {
+    LevelColsArgs lev[kMaxMulti];
+    int first[kMaxMulti + 1];
+    int count;
+};
+template <int NB, bool BLU>
+__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_multi_level_cols_kernel(const MultiColsArgs ma) {
+    int i = 0;
+    while (i + 1 < ma.count && (int)blockIdx.x >= ma.first[i + 1]) ++i;      // (uniform)
+    level_cols_body<NB, BLU>(ma.lev[i], (int)blockIdx.x - ma.first[i], blockIdx.y);
+}
+
 // per-line output base (in elements of h*w planes): plane map applied once per row, not per element
 __device__ __forceinline__ void line_bases(size_t *base, int lines, long long row0, int h, int w, const PlaneMap &pm, int NB) {
     for (int l = threadIdx.x; l < lines; l += kThreads) {
@@ -502,11 +522,11 @@ __device__ __forceinline__ void zero_row_padding(float2 *buf, int lines, int pit
 
 // rows of T -> inverse row FFT -> (phase, amplitude) or the complex coefficient (coeff_to_values, src/train/pyramid.py:63-69)
 template <int NB, bool BLU>
-__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_polar_kernel(const RowsPolarArgs a) {
+__device__ __forceinline__ void rows_polar_body(const RowsPolarArgs &a, const int block_x) {
     using namespace vfi::fft;
     extern __shared__ float2 buf[];
     const int w = a.pw.n, m = a.pw.m, pitch = padded_length(m);
-    const long long row0 = (long long)blockIdx.x * a.lines;
+    const long long row0 = (long long)block_x * a.lines;
     const int lines = (int)(a.rows - row0 < a.lines ? a.rows - row0 : a.lines);
     float2 *twl = buf + (size_t)a.lines * pitch;
     size_t *base = reinterpret_cast<size_t *>(twl + a.pw.tw_len);
@@ -576,6 +596,22 @@ __global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_polar_kerne
             if ((threadIdx.x & 63) == 0 && t < a.groups && m > 0.0f) atomicMax(a.amp_max + t, __float_as_uint(m));
         }
     }
+}
+
+template <int NB, bool BLU>
+__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_rows_polar_kernel(const RowsPolarArgs a) {
+    rows_polar_body<NB, BLU>(a, blockIdx.x);
+}
+struct MultiRowsArgs {
+    RowsPolarArgs lev[kMaxMulti];
+    int first[kMaxMulti + 1];
+    int count;
+};
+template <int NB, bool BLU>
+__global__ __launch_bounds__(kThreads, kThreads / 128) void pyr_multi_rows_polar_kernel(const MultiRowsArgs ma) {
+    int i = 0;
+    while (i + 1 < ma.count && (int)blockIdx.x >= ma.first[i + 1]) ++i;      // (uniform)
+    rows_polar_body<NB, BLU>(ma.lev[i], (int)blockIdx.x - ma.first[i]);
 }
 
 __global__ void pyr_amp_max_finish_kernel(const unsigned *__restrict__ bits, float *__restrict__ out, int count, float eps) {
@@ -1061,9 +1097,77 @@ static int pyr_analyze_impl(vfi_pyr_plan *p, const float *img, int N, float *hig
         return vfi::fail(VFI_ERR_LAUNCH, "vfi_pyr_analyze_max: memset");
     if ((rc = fft2d_r2c(p, img, p->half0, N, s))) return rc;
     debug_scan(p->half0, (size_t)N * H * (W / 2 + 1) * 2, s, "half spectrum", -1);
+    // ---- the small levels (<= 40 k coefficients per band: from 135 x 240 down at 1080p) as FOUR launches on the generic LDS
+    // engine instead of two per level: column passes of the smooth / Bluestein heights, row passes of the smooth / Bluestein
+    // widths; every level has its own region of T.  VFI_PYR_MULTI=0: one launch pair per level (A/B aid)
+    unsigned long long multi_mask = 0;
+    {
+        static const bool multi_on = !(getenv("VFI_PYR_MULTI") && atoi(getenv("VFI_PYR_MULTI")) == 0);
+        // (coarsest first, while their T regions fit into the workspace together: it is sized for ONE level, the finest)
+        const size_t cap = (size_t)p->max_images * nb * H * p->tpitch_max;
+        size_t need = 0;
+        int cnt = 0;
+        for (int k = p->nlev - 1; k >= 0 && cnt < kMaxMulti; --k) {
+            if (!((level_mask >> k) & 1ull)) continue;
+            const size_t t = (size_t)N * nb * p->lev[k].h * p->lev[k].w;
+            if ((long long)p->lev[k].h * p->lev[k].w > 40000 || need + t > cap) break;
+            multi_mask |= 1ull << k; need += t; ++cnt;
+        }
+        if (!multi_on || cnt < 2) multi_mask = 0;
+    }
+    if (multi_mask) {
+        using namespace vfi::fft;
+        MultiColsArgs mc[2];      // [bluestein]
+        MultiRowsArgs mr[2];
+        size_t clds[2] = {0, 0}, rlds[2] = {0, 0};
+        for (int b = 0; b < 2; ++b) { mc[b].count = 0; mc[b].first[0] = 0; mr[b].count = 0; mr[b].first[0] = 0; }
+        size_t toff = 0;          // (float2 elements into p->bands)
+        for (int k = 0; k < p->nlev; ++k) {
+            if (!((multi_mask >> k) & 1ull)) continue;
+            const Level &L = p->lev[k];
+            VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
+                        "vfi_pyr_analyze: null output for level %d", k);
+            Plan1D ph, pw;
+            if ((rc = get_fft(p, L.h, &ph)) || (rc = get_fft(p, L.w, &pw))) return rc;
+            float2 *T = p->bands + toff;
+            toff += (size_t)N * nb * L.h * L.w;
+            int tile, bpp;
+            level_tiling(ph, L.w, &tile, &bpp);
+            MultiColsArgs &c = mc[ph.bluestein ? 1 : 0];
+            c.lev[c.count] = LevelColsArgs{ph, p->half0, T, L.P_a, L.h, L.w, H, W, tile, bpp};
+            c.first[c.count + 1] = c.first[c.count] + 8 * ceil_div(ceil_div(L.w, tile), 8);
+            ++c.count;
+            clds[ph.bluestein ? 1 : 0] = std::max(clds[ph.bluestein ? 1 : 0], level_lds_bytes(ph, tile, bpp));
+            const long long rows = (long long)N * nb * L.h;
+            int lines = rows_per_group(pw, rows);
+            if (lines > 256) lines = 256;
+            MultiRowsArgs &r = mr[pw.bluestein ? 1 : 0];
+            r.lev[r.count] = RowsPolarArgs{pw, T, phase[k], amp ? amp[k] : nullptr, make_map(plane_index, k, N, nb, flags), rows, L.h, lines,
+                                           1.0f / ((float)L.h * (float)L.w), phase_scale, amp_max ? p->amp_bits + (size_t)k * groups : nullptr, groups};
+            r.first[r.count + 1] = r.first[r.count] + (int)((rows + lines - 1) / lines);
+            ++r.count;
+            rlds[pw.bluestein ? 1 : 0] = std::max(rlds[pw.bluestein ? 1 : 0], row_lds_bytes(pw, lines, (size_t)lines * sizeof(size_t)));
+        }
+        if (mc[0].count) {
+            allow_big_lds<pyr_multi_level_cols_kernel<4, false>>();
+            hipLaunchKernelGGL((pyr_multi_level_cols_kernel<4, false>), dim3(mc[0].first[mc[0].count], N), dim3(kThreads), clds[0], s, mc[0]);
+        }
+        if (mc[1].count) {
+            allow_big_lds<pyr_multi_level_cols_kernel<4, true>>();
+            hipLaunchKernelGGL((pyr_multi_level_cols_kernel<4, true>), dim3(mc[1].first[mc[1].count], N), dim3(kThreads), clds[1], s, mc[1]);
+        }
+        if (mr[0].count) {
+            allow_big_lds<pyr_multi_rows_polar_kernel<4, false>>();
+            hipLaunchKernelGGL((pyr_multi_rows_polar_kernel<4, false>), dim3(mr[0].first[mr[0].count]), dim3(kThreads), rlds[0], s, mr[0]);
+        }
+        if (mr[1].count) {
+            allow_big_lds<pyr_multi_rows_polar_kernel<4, true>>();
+            hipLaunchKernelGGL((pyr_multi_rows_polar_kernel<4, true>), dim3(mr[1].first[mr[1].count]), dim3(kThreads), rlds[1], s, mr[1]);
+        }
+    }
     for (int k = 0; k < p->nlev; ++k) {
         const Level &L = p->lev[k];
-        if (!((level_mask >> k) & 1ull)) continue;      // (the levels read the half spectrum directly: nothing to pass along)
+        if (!((level_mask >> k) & 1ull) || ((multi_mask >> k) & 1ull)) continue;      // (the levels read the half spectrum directly: nothing to pass along)
         VFI_REQUIRE(phase[k] && ((flags & VFI_PYR_COMPLEX_COEFF) || amp[k]), VFI_ERR_INVALID_ARG,
                     "vfi_pyr_analyze: null output for level %d", k);
         using namespace vfi::fft;
