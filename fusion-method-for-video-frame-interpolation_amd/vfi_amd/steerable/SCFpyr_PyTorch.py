@@ -3,7 +3,8 @@
 src/train/pyramid.py:28-33 and calls at :37,44.  Coefficient layout as the reference expects it:
 coeff = [hi (N,H,W), [nbands x (N,h,w,2)] per level finest first, lo (N,hL,wL)] (pyramid.py:56-61).
 
-Backed by one plan per (H, W) in libvfi_hip.so (level geometry, mask tables, hipFFT plans, workspace).
+Backed by one plan per (H, W) in libvfi_hip.so (level geometry, mask tables, the tables of the hand-written FFT
+engines -- no FFT library is linked --, workspace).
 """
 import ctypes
 

@@ -22,8 +22,16 @@ def seeded_weights(seed=0):
 
 
 @torch.no_grad()
-def interp(rgb1, rgb2, weights, output_baseline=False, timings=None):
-    """rgb1, rgb2: (3,H,W) float32 in [0,1] -> dict of tensors (same keys as the product's FusionInterpolator)."""
+def interp(rgb1, rgb2, weights, output_baseline=False, timings=None, hooks=None, reuse=None, stop_after=None,
+           keep_stages=False):
+    """rgb1, rgb2: (3,H,W) float32 in [0,1] -> dict of tensors (same keys as the product's FusionInterpolator).
+
+    Test aids (tests/test_pipeline_gpu.py, the explained-set check of `ada_uncertainty`): `hooks` maps a stage name
+    ("vals_input": PhaseNet's input pyramid, :172-175; "vals_second": the analysis of (ada_pred, rgb_pred), :198-203) to a
+    function value -> value applied before the stage is consumed; `reuse` = the dict an earlier call returned, whose
+    AdaCoF #1 outputs and first analysis are taken over instead of recomputed; `stop_after="ada_uncertainty"` returns
+    once both maps exist; `keep_stages` adds the hooked values as the stages consumed them ("_vals_input", "_vals_second")
+    and PhaseNet's input before its hook ("_vals_input_raw", what `reuse` needs) to the returned dict."""
     tic = time.perf_counter()
 
     def lap(name):
@@ -40,13 +48,20 @@ def interp(rgb1, rgb2, weights, output_baseline=False, timings=None):
     lab1, lab2 = color_cpu.rgb2lab_single(rgb1), color_cpu.rgb2lab_single(rgb2)   # :148-149
     f1, f2 = rgb1.unsqueeze(0), rgb2.unsqueeze(0)
     lap("lab")
-    _, _, ada_pred, flow_var_map = adacof(f1, f2)                                  # :156
-    ada_pred = ada_pred[0]
-    flow_var_map = flow_var_map.squeeze(1)
-    lap("adacof")
-    vals_batch = pyr.filter(torch.cat((lab1, lab2), 0).float())                    # :172
-    vals_input = layout_cpu.get_concat_layers_inf(layout_cpu.separate_vals(vals_batch, 2))
-    lap("pyramid")
+    hooks = hooks or {}
+    if reuse is not None:
+        ada_pred, flow_var_map, vals_input = reuse["ada_pred"][0], reuse["flow_var_map"].squeeze(1), reuse["_vals_input_raw"]
+    else:
+        _, _, ada_pred, flow_var_map = adacof(f1, f2)                              # :156
+        ada_pred = ada_pred[0]
+        flow_var_map = flow_var_map.squeeze(1)
+        lap("adacof")
+        vals_batch = pyr.filter(torch.cat((lab1, lab2), 0).float())                # :172
+        vals_input = layout_cpu.get_concat_layers_inf(layout_cpu.separate_vals(vals_batch, 2))
+        lap("pyramid")
+    vals_input_raw = vals_input
+    if "vals_input" in hooks:
+        vals_input = hooks["vals_input"](vals_input)
     normed, state = nets_cpu.phasenet_normalize(vals_input)                        # :175
     vals_pred = nets_cpu.phasenet_forward(weights["phasenet"], normed, state, height)   # :185
     lap("phasenet")
@@ -56,6 +71,8 @@ def interp(rgb1, rgb2, weights, output_baseline=False, timings=None):
     phase_pred = rgb_pred.clone()
     lap("lab")
     vals = pyr.filter(torch.cat((ada_pred, rgb_pred), 0).float())                  # :198-203
+    if "vals_second" in hooks:
+        vals = hooks["vals_second"](vals)
     vals_ada, vals_ph = layout_cpu.separate_vals(vals, 2)
     h_freq = pyr.inv_filter(layout_cpu.get_last_value_levels(vals_ada, 1))
     h_freq_ph = pyr.inv_filter(layout_cpu.get_last_value_levels(vals_ph, 1))
@@ -67,6 +84,13 @@ def interp(rgb1, rgb2, weights, output_baseline=False, timings=None):
     ada_uncertainty = uncertainty_cpu.ada_uncertainty_tail(freq)                   # :217-225
     lap("median")
     pp = phase_pred.unsqueeze(0)
+    if keep_stages:
+        extra = {"_vals_input_raw": vals_input_raw, "_vals_input": vals_input, "_vals_second": vals}
+    else:
+        extra = {}
+    if stop_after == "ada_uncertainty":
+        return dict(extra, phase_pred=pp, ada_pred=ada_pred.unsqueeze(0), flow_var_map=flow_var_map.unsqueeze(1),
+                    phase_uncertainty=phase_uncertainty, ada_uncertainty=ada_uncertainty)
     _, _, b1, _ = adacof(f1, pp)                                                   # :229-238
     _, _, b2, _ = adacof(pp, f2)
     _, _, base, _ = adacof(b1, b2)
@@ -85,4 +109,5 @@ def interp(rgb1, rgb2, weights, output_baseline=False, timings=None):
     maps = torch.stack([ada_uncertainty, phase_uncertainty, flow_var_map], 1).float()
     out["final"] = nets_cpu.fusionnet_forward(weights["fusionnet"], base, out["ada_pred"], pp, other, maps, 0)   # :330
     lap("fusionnet")
+    out.update(extra)
     return out

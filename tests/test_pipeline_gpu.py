@@ -20,6 +20,21 @@ def _psnr(a, b):
     return 10 * math.log10(1.0 / max(float(((a - b) ** 2).mean()), 1e-30))
 
 
+# per-stage dB of the full-size parity tests, written to gpurun_out/parity_full_size.json (copied to profiles/ by hand)
+_PARITY_LOG = {}
+
+
+def _write_parity_log():
+    import json
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_full_size.json"), "w") as f:
+            json.dump(_PARITY_LOG, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def _models(device, weights):
     args = types.SimpleNamespace(model="vfi_amd.fusion_net.fusion_adacofnet", kernel_size=5, dilation=1, gpu_id=0)
     adacof = Model(args)
@@ -31,30 +46,124 @@ def _models(device, weights):
     return FusionInterpolator(adacof, fusion, weights["phasenet"], device)
 
 
+# The reference's formula for `ada_uncertainty` (src/fusion_net/interpolate_twoframe.py:217-225: |phase| and |amplitude|
+# differences of the six coarsest levels -> reconstruction -> x150 -> distance from a 50x50 median) loses CONDITIONING_DB of
+# agreement between its input images and the map (tests/test_oracle_conditioning.py measures 50-57 dB on the oracle alone).
+CONDITIONING_DB = 57.0
+ADA_FLOOR_DB = 48.0
+
+
 def _assert_stage_parity(got, ref, f1_true, label):
     """Every stage output of the fused frame against the oracle pipeline: >= 60 dB on [0,1] images.
 
-    `ada_uncertainty` is checked in two parts, because the reference's own formula for it (|phase| and |amplitude|
-    differences of the six coarsest levels -> reconstruction -> x150 -> distance from a 50x50 median,
-    src/fusion_net/interpolate_twoframe.py:217-225) amplifies a perturbation of its INPUT images by ~50 dB: the oracle fed
-    two `phase_pred` images that agree to 125 dB returns maps that agree to only ~73 dB
-    (tests/test_oracle_conditioning.py measures this on the CPU).  So (a) the stage itself -- the oracle's
-    uncertainty_maps() applied to the product's OWN ada_pred / phase_pred -- must reproduce the product's map at >= 60 dB
-    (it does at ~99 dB), and (b) end to end, where the two pipelines' phase_pred differ by fp32 rounding (110-127 dB), the
-    map must stay >= 40 dB.  Everything downstream of it (`final`) is held to the 60 dB bar again."""
+    `ada_uncertainty` is checked in two parts, because its formula amplifies a perturbation of its INPUT images by
+    50-57 dB (CONDITIONING_DB above).  (a) The stage itself -- the oracle's uncertainty_maps() applied to the product's OWN
+    ada_pred / phase_pred -- must reproduce the product's map at >= 60 dB (it does at ~99 dB).  (b) End to end the bound is
+    derived from what the stage was fed: PSNR(phase_pred) - CONDITIONING_DB, never below ADA_FLOOR_DB; at 1280x720 and
+    1920x1080 `_assert_ada_uncertainty_explained` below additionally restores the 60 dB bar on the whole map once the
+    phase coefficients that wrapped to the other side of the +-pi cut are accounted for.  Everything downstream of the map
+    (`final`) is held to the 60 dB bar."""
     from oracle import layout_cpu, pyramid_cpu, uncertainty_cpu
-    report = {k: _psnr(got[k].cpu(), ref[k]) for k in ref}
+    report = {k: _psnr(got[k].cpu(), ref[k]) for k in ref if not k.startswith("_")}
     h, w = ref["final"].shape[-2:]
     opyr = pyramid_cpu.Pyramid(layout_cpu.calc_pyr_height(h, w), 4, np.sqrt(2))
     pu, au = uncertainty_cpu.uncertainty_maps(opyr, got["ada_pred"][0].cpu(), got["phase_pred"][0].cpu())
     report["ada_uncertainty | own inputs"] = _psnr(got["ada_uncertainty"].cpu(), au)
     report["phase_uncertainty | own inputs"] = _psnr(got["phase_uncertainty"].cpu(), pu)
     print(label, report)
+    ada_bound = max(ADA_FLOOR_DB, min(60.0, min(report["phase_pred"], report["ada_pred"]) - CONDITIONING_DB))
     for k, v in report.items():
-        assert v >= (40.0 if k == "ada_uncertainty" else 60.0), (k, report)
+        assert v >= (ada_bound if k == "ada_uncertainty" else 60.0), (k, ada_bound, report)
     # |PSNR(HIP, GT) - PSNR(CPU, GT)| <= 0.01 dB on the analytic middle frame
     assert abs(_psnr(got["final"].cpu()[0], f1_true) - _psnr(ref["final"][0], f1_true)) <= 0.01
     return report
+
+
+def _wrapped(p_ref, a_ref, p_gpu, a_gpu):
+    """Coefficients whose PHASE VALUE differs by about 2 pi between the two pipelines although the complex coefficient
+    agrees to the pyramid's tolerance (tests/test_pyramid_gpu.py: 5e-5 of the level's largest amplitude): atan2 put them
+    on opposite sides of the +-pi cut.  Returns (mask of those, number of coefficients whose phase differs by more than 1 rad
+    WITHOUT being such a wrap)."""
+    scale = max(1e-3, float(a_ref.max()))
+    far = (p_ref - p_gpu).abs() > 1.0
+    same_coeff = (torch.polar(a_ref, p_ref) - torch.polar(a_gpu, p_gpu)).abs() <= 5e-5 * scale
+    near_cut = (p_ref.abs() > math.pi - 1e-2) & (p_gpu.abs() > math.pi - 1e-2)
+    wrap = far & same_coeff & near_cut
+    # a phase that is far off WITHOUT the wrap excuse is only acceptable where the coefficient is (numerically) zero:
+    # there atan2 returns noise in both pipelines
+    unexplained = far & ~wrap & (a_ref > 2e-4 * scale)
+    return wrap, int(unexplained.sum())
+
+
+def _assert_ada_uncertainty_explained(run, got, ref, f0, f2, weights, label):
+    """The explained-set check of `ada_uncertainty` (reference src/fusion_net/interpolate_twoframe.py:168-225).
+
+    atan2 is discontinuous at +-pi: a coefficient within rounding distance of the cut may come out as +pi in one fp32
+    pipeline and -pi in the other.  Such a wrap is NOT an error of the coefficient, but it (1) changes PhaseNet's input by
+    2 (in units of pi) at that coefficient, hence `phase_pred` slightly, and (2) changes |phase difference| of the second
+    analysis by 2 pi; the map's formula then amplifies either by ~50 dB.  This test finds those coefficients by comparing the
+    product's phases with the oracle's, asserts (i) that every large phase difference IS such a wrap (the complex
+    coefficient agrees to 5e-5 of the level's scale and both phases lie within 1e-2 of the cut), (ii) that they are few
+    (bound below), and (iii) that the oracle, re-run from PhaseNet's input onwards with exactly those coefficients' phases
+    set to the product's side of the cut, reproduces the product's map at >= 60 dB on the WHOLE frame."""
+    from vfi_amd import ops
+    device = got["final"].device
+    h, w = f0.shape[1:]
+    pyr, phase_net = run._state(h, w)
+    nlev = pyr.height - 2
+    # (1) PhaseNet's input as the product computed it (Pyramid.filter into the concat layout, phase / pi)
+    lab12 = torch.empty((6, h, w), dtype=torch.float32, device=device)
+    ops.rgb2lab(f0.to(device), out=lab12[:3])
+    ops.rgb2lab(f2.to(device), out=lab12[3:])
+    vals, _bufs, _ = pyr.filter(lab12, concat_frames=2, phase_scale=1.0 / math.pi, amp_max_eps=phase_net.eps)
+    rin = ref["_vals_input_raw"]
+    n_coeff, wraps1, bad1, patched = 0, 0, 0, []
+    for k in range(nlev):                                     # coarsest first, (3, 8, h_k, w_k)
+        p_gpu, a_gpu = vals.phase[k].cpu() * math.pi, vals.amplitude[k].cpu()
+        wrap, bad = _wrapped(rin.phase[k], rin.amplitude[k], p_gpu, a_gpu)
+        n_coeff += wrap.numel()
+        wraps1 += int(wrap.sum())
+        bad1 += bad
+        patched.append(torch.where(wrap, p_gpu, rin.phase[k]))
+    del vals, _bufs
+    type_ = type(rin)
+    hook_in = lambda v: type_(v.high_level, patched, v.amplitude, v.low_level)
+
+    # (2) the second analysis (ada_pred, rgb_pred), six coarsest levels, as the product computes it
+    coarse = min(6, nlev)
+    mask = ((1 << coarse) - 1) << (nlev - coarse)
+    vb = pyr.filter(torch.cat((got["ada_pred"][0], got["phase_pred"][0]), 0), level_mask=mask, want_high=False)
+    second = {k: (vb.phase[k].cpu(), vb.amplitude[k].cpu()) for k in range(nlev - coarse, nlev)}   # finest first, (24, 1, h_k, w_k)
+    del vb
+    stats = {"wraps2": 0, "bad2": 0, "n2": 0}
+
+    def hook_second(v):
+        phase = list(v.phase)
+        for k, (p_gpu, a_gpu) in second.items():
+            wrap, bad = _wrapped(v.phase[k], v.amplitude[k], p_gpu.reshape(v.phase[k].shape), a_gpu.reshape(v.phase[k].shape))
+            stats["wraps2"] += int(wrap.sum())
+            stats["bad2"] += bad
+            stats["n2"] += wrap.numel()
+            phase[k] = torch.where(wrap, p_gpu.reshape(v.phase[k].shape), v.phase[k])
+        return type(v)(v.high_level, phase, v.amplitude, v.low_level)
+
+    ref2 = pipeline_cpu.interp(f0, f2, weights, hooks={"vals_input": hook_in, "vals_second": hook_second}, reuse=ref,
+                               stop_after="ada_uncertainty")
+    rep = {"coefficients": n_coeff, "wrapped (PhaseNet input)": wraps1, "far but not wrapped (PhaseNet input)": bad1,
+           "coefficients (2nd analysis, 6 coarsest)": stats["n2"], "wrapped (2nd analysis)": stats["wraps2"],
+           "far but not wrapped (2nd analysis)": stats["bad2"],
+           "phase_pred vs oracle": _psnr(got["phase_pred"].cpu(), ref["phase_pred"]),
+           "phase_pred vs oracle with the wraps applied": _psnr(got["phase_pred"].cpu(), ref2["phase_pred"]),
+           "ada_uncertainty vs oracle": _psnr(got["ada_uncertainty"].cpu(), ref["ada_uncertainty"]),
+           "ada_uncertainty vs oracle with the wraps applied": _psnr(got["ada_uncertainty"].cpu(), ref2["ada_uncertainty"])}
+    print(label, rep)
+    assert bad1 == 0 and stats["bad2"] == 0, rep
+    # the bound on the explained set: a wrap needs a phase within rounding distance (~1e-5 rad at the amplitudes that
+    # matter) of the cut, i.e. a fraction ~1e-5 / pi of uniformly distributed phases: 3e-6 n; allow 1e-5 n + 4
+    assert wraps1 <= 1e-5 * n_coeff + 4 and stats["wraps2"] <= 1e-5 * stats["n2"] + 4, rep
+    assert rep["ada_uncertainty vs oracle with the wraps applied"] >= 60.0, rep
+    assert rep["phase_pred vs oracle with the wraps applied"] >= 60.0, rep
+    return rep
 
 
 @pytest.mark.parametrize("h,w", [(128, 160), (96, 96)])
@@ -96,13 +205,11 @@ def test_fused_frame_full_size_properties(h, w, device):
     out2 = _models(device, weights)(f0, f2, output_baseline=True)
     for k, v in out.items():
         assert torch.equal(v, out2[k]), k
-    # identical frames: the PhaseNet branch must reproduce the pyramid round trip of a blend of equal inputs, i.e.
-    # phase/amplitude blends of equal values are those values whatever the (random) network predicts for alpha/beta
-    same = run(f0, f0)
-    assert torch.equal(run(f0, f0)["final"], same["final"])          # deterministic
-    # frame order symmetry of the sampler's mask: swapping the inputs swaps the two sampling sides
-    m1 = run(f0, f2)["flow_var_map"]
-    assert m1.shape == (1, 1, h, w)
+    # the same interpolator called again (plans, packed weights and workspaces reused) gives the same bits
+    again = run(f0, f2, output_baseline=True)
+    for k, v in out.items():
+        assert torch.equal(v, again[k]), k
+    assert out["flow_var_map"].shape == (1, 1, h, w)
 
 
 def test_fused_frame_runs_at_4k(device):
@@ -219,11 +326,13 @@ def test_fused_frame_720p_matches_oracle(pair_720, device):
     """configs[3] (the full fused frame) at 1280x720, every stage output against the oracle pipeline."""
     f0, f1_true, f2 = pair_720
     weights = pipeline_cpu.seeded_weights(0)
-    ref = pipeline_cpu.interp(f0, f2, weights, output_baseline=True)
+    ref = pipeline_cpu.interp(f0, f2, weights, output_baseline=True, keep_stages=True)
     run = _models(device, weights)
     got = run(f0.to(device), f2.to(device), output_baseline=True)
     torch.cuda.synchronize()
-    _assert_stage_parity(got, ref, f1_true, "configs[3] fused frame 720p vs oracle:")
+    _PARITY_LOG["720p"] = _assert_stage_parity(got, ref, f1_true, "configs[3] fused frame 720p vs oracle:")
+    _PARITY_LOG["720p explained"] = _assert_ada_uncertainty_explained(run, got, ref, f0, f2, weights, "720p ada_uncertainty, explained set:")
+    _write_parity_log()
 
 
 def test_fused_frame_1080p_matches_oracle(device):
@@ -235,11 +344,13 @@ def test_fused_frame_1080p_matches_oracle(device):
     f0, f1_true, f2 = (torch.from_numpy(x) for x in synth.translating_pair(11, h, w))
     weights = pipeline_cpu.seeded_weights(0)
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
-    ref = pipeline_cpu.interp(f0, f2, weights, output_baseline=True)
+    ref = pipeline_cpu.interp(f0, f2, weights, output_baseline=True, keep_stages=True)
     run = _models(device, weights)
     got = run(f0.to(device), f2.to(device), output_baseline=True)
     torch.cuda.synchronize()
-    _assert_stage_parity(got, ref, f1_true, "configs[3] fused frame 1080p vs oracle:")
+    _PARITY_LOG["1080p"] = _assert_stage_parity(got, ref, f1_true, "configs[3] fused frame 1080p vs oracle:")
+    _PARITY_LOG["1080p explained"] = _assert_ada_uncertainty_explained(run, got, ref, f0, f2, weights, "1080p ada_uncertainty, explained set:")
+    _write_parity_log()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -27,7 +27,9 @@ def _psnr(a, b):
     return 10 * math.log10(1.0 / max(float(((a - b) ** 2).mean()), 1e-30))
 
 
-@pytest.mark.parametrize("h,w", [(64, 96), (90, 120), (128, 128), (65, 77)])
+# (720, 1280) and (1080, 1920): BASELINE.json's sizes at COEFFICIENT level, N = 6 -- the team kernels of the long columns,
+# the Bluestein levels (764 x 1358 ...) and the multi-level launches of the small levels are on the path only there
+@pytest.mark.parametrize("h,w", [(64, 96), (90, 120), (128, 128), (65, 77), (720, 1280), (1080, 1920)])
 def test_filter_matches_oracle(h, w, device):
     height = layout_cpu.calc_pyr_height(h, w)
     img = _images(1, 1, h, w)                                     # 6 channel-images
@@ -49,7 +51,7 @@ def test_filter_matches_oracle(h, w, device):
         assert p.abs().max().item() <= math.pi + 1e-6
 
 
-@pytest.mark.parametrize("h,w", [(64, 96), (90, 120), (256, 256)])
+@pytest.mark.parametrize("h,w", [(64, 96), (90, 120), (256, 256), (720, 1280), (1080, 1920)])
 def test_round_trip_and_inverse_vs_oracle(h, w, device):
     height = layout_cpu.calc_pyr_height(h, w)
     img = _images(2, 1, h, w)[:3]
