@@ -93,6 +93,10 @@ bool winograd4_suits(const ConvArgs &a, int N);
 int launch_winograd4(const ConvArgs &a, int N, hipStream_t s);
 void launch_pack_winograd4(const float *w_oihw, const float *scale, float *packed, int Cout, int Cin, int Cin_pad, int Cout_pad,
                            hipStream_t s);
+// vfi_conv_winograd4m.hip: the same work items on one wave per SIMD with 32 output channels per wave (args as prepared by
+// launch_winograd4)
+bool winograd4m_enabled();
+int launch_winograd4m(const ConvArgs &prepared, hipStream_t s);
 
 }  // namespace conv
 }  // namespace vfi

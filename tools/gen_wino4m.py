@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Generator of csrc/vfi_conv_winograd4m_body.h: the hand-scheduled chunk body of the F(4x4,3x3) Winograd kernel with
+M = 32 output channels per wave (one wave per SIMD, accumulators in the AGPR file).
+
+One *chunk* = 4 input channels of one 16 x 64 output tile x 32 output channels.  Wave w owns tile row w (sixteen 4x4
+tiles); lane (n16 = lane & 15, k4 = lane >> 4) holds the raw 6x6 patch of tile n16 for input channel k4, transforms it
+(V = B^T d B, 144 operations) and feeds V's 36 entries to 72 v_mfma_f32_16x16x4_f32 (36 positions x two 16-channel
+halves), i.e. 2 transform operations per MFMA instead of the 4 of the M = 16 kernel (vfi_conv_winograd4.hip).
+
+The body of chunk c is ONE asm statement that
+  * issues the 72 MFMAs of chunk c (operands: V rows from registers, weights U from registers),
+  * in their shadow: reads chunk c+1's patch and weights from LDS, runs chunk c+1's column pass (B^T d), the row
+    passes of chunk c (row i+1 during row i's MFMAs) and chunk c+1's row 0, and requests chunk c+4 from memory
+    (LDS-DMA, buffer_load ... lds) into the ring slot chunk c vacated.
+Every vector register the body touches is a FIXED physical register; the C++ side binds its variables to exactly these
+registers with "{vN}" / "{a[N:M]}" constraints, so the compiler knows what is live where (see the operand macro emitted
+at the end) and the text below can name registers literally.
+
+Two bodies are emitted (P = 0 / 1): the patch sets swap roles every chunk.  tools/sim_wino4m.py interprets the emitted
+text on the CPU (numpy over the 64 lanes) against a direct Winograd evaluation; tests/test_conv_host.py runs it.
+"""
+import os
+import sys
+
+ROWP, PLANE_S, IN_FLOATS, W_FLOATS, BN, NGRP = 68, 1280, 5120, 4608, 32, 9
+BUF_BYTES = (IN_FLOATS + W_FLOATS) * 4
+NBUF = 4
+
+# ---- register map (VGPR numbers) -------------------------------------------------------------------------------------
+TMP = [60, 61, 62, 63]          # column-pass temporaries
+RTMP = [64, 65]                 # row-pass temporaries
+PADDR, WADDR = 66, 67           # LDS byte addresses of this chunk's reads (patch / weights)
+TSET = [68, 104]                # patch sets A, B: row r at base + 6 r (6 registers)
+UBASE = 140                     # u[h][g] (4 positions of group g, 16-channel half h) at UBASE + 4 (9 h + g)
+VBUF = [212, 218]               # V rows: buffer 0 / 1 (6 registers each)
+ACCV = 224                      # accumulators 64..71 (VGPRs); 0..63 are a[0:255]
+FIRST_FREE = 60                 # the compiler keeps to v0 .. v59 inside the chunk loop
+
+
+def treg(s, r, j):
+    return TSET[s] + 6 * r + j
+
+
+def ureg(h, p):
+    return UBASE + 4 * (9 * h + p // 4) + p % 4
+
+
+def acc_name(h, p):
+    k = 36 * h + p
+    if k < 64:
+        return "a[%d:%d]" % (4 * k, 4 * k + 3)
+    return "v[%d:%d]" % (ACCV + 4 * (k - 64), ACCV + 4 * (k - 64) + 3)
+
+
+class Emitter:
+    """Instruction list with the LDS-read bookkeeping: a load's destination registers are pending until a
+    `s_waitcnt lgkmcnt(k)` that retires it; k = number of LDS operations issued after it (in-order return)."""
+
+    def __init__(self, pending_in=()):
+        self.lines = []
+        self.pending = [set(regs) for regs in pending_in]      # oldest first, one entry per outstanding LDS read
+        self.lds_ops = 0
+
+    def raw(self, text):
+        self.lines.append(text)
+
+    def need(self, regs):
+        regs = set(regs)
+        last = -1
+        for i, p in enumerate(self.pending):
+            if p & regs:
+                last = i
+        if last >= 0:
+            k = len(self.pending) - 1 - last
+            self.raw("s_waitcnt lgkmcnt(%d)" % min(k, 15))
+            self.pending = self.pending[last + 1:] if k <= 15 else self.pending[len(self.pending) - 15:]
+
+    def valu(self, text, reads, writes):
+        self.need(list(reads) + list(writes))
+        self.raw(text)
+
+    def ds_read(self, width, dst, addr, offset):
+        n = width // 32
+        regs = list(range(dst, dst + n))
+        self.need(regs)
+        self.raw("ds_read_b%d v[%d:%d], v%d offset:%d" % (width, dst, dst + n - 1, addr, offset))
+        self.pending.append(set(regs))
+
+    def mfma(self, h, p, vb):
+        a, b = ureg(h, p), vb
+        self.need([a, b])
+        acc = acc_name(h, p)
+        self.raw("v_mfma_f32_16x16x4_f32 %s, v%d, v%d, %s" % (acc, a, b, acc))
+
+
+def transform_ops(x, out, tmp, five):
+    """B^T x for six samples (12 operations, the order of vfi_conv_winograd4.hip: input_transform6) -- x: input
+    registers, out: output registers (may alias x only where IN_PLACE order allows, see column_pass), tmp: temporaries."""
+    raise NotImplementedError
+
+
+def column_pass_ops(s, j, five):
+    """In place on column j of patch set s: 12 operations, 4 temporaries, no moves (the order matters: an output
+    overwrites an input only after that input's last use)."""
+    x = [treg(s, r, j) for r in range(6)]
+    A, B, C, D = TMP
+    ops = [
+        ("v_fma_f32 v%d, -%s, v%d, v%d" % (C, five, x[2], x[4]), [x[2], x[4]], [C]),
+        ("v_fma_f32 v%d, 4.0, v%d, v%d" % (x[0], x[0], C), [x[0], C], [x[0]]),                     # t0
+        ("v_fma_f32 v%d, -4.0, v%d, v%d" % (A, x[2], x[4]), [x[2], x[4]], [A]),                    # p
+        ("v_fma_f32 v%d, -4.0, v%d, v%d" % (B, x[1], x[3]), [x[1], x[3]], [B]),                    # q
+        ("v_sub_f32 v%d, v%d, v%d" % (C, x[4], x[2]), [x[4], x[2]], [C]),                          # r
+        ("v_sub_f32 v%d, v%d, v%d" % (D, x[3], x[1]), [x[3], x[1]], [D]),                          # s
+        ("v_fma_f32 v%d, -%s, v%d, v%d" % (x[5], five, x[3], x[5]), [x[3], x[5]], [x[5]]),
+        ("v_fma_f32 v%d, 4.0, v%d, v%d" % (x[5], x[1], x[5]), [x[1], x[5]], [x[5]]),               # t5
+        ("v_add_f32 v%d, v%d, v%d" % (x[1], A, B), [A, B], [x[1]]),                                # t1
+        ("v_sub_f32 v%d, v%d, v%d" % (x[2], A, B), [A, B], [x[2]]),                                # t2
+        ("v_fma_f32 v%d, 2.0, v%d, v%d" % (x[3], D, C), [D, C], [x[3]]),                           # t3
+        ("v_fma_f32 v%d, -2.0, v%d, v%d" % (x[4], D, C), [D, C], [x[4]]),                          # t4
+    ]
+    return ops
+
+
+def row_pass_ops(s, i, vb, five):
+    """Row i of patch set s (after its column pass) -> V row in buffer vb: 12 operations, 2 temporaries."""
+    x = [treg(s, i, j) for j in range(6)]
+    v = [vb + j for j in range(6)]
+    E, F = RTMP
+    ops = [
+        ("v_fma_f32 v%d, -%s, v%d, v%d" % (v[0], five, x[2], x[4]), [x[2], x[4]], [v[0]]),
+        ("v_fma_f32 v%d, 4.0, v%d, v%d" % (v[0], x[0], v[0]), [x[0], v[0]], [v[0]]),               # v0
+        ("v_fma_f32 v%d, -4.0, v%d, v%d" % (E, x[2], x[4]), [x[2], x[4]], [E]),                    # p
+        ("v_fma_f32 v%d, -4.0, v%d, v%d" % (v[2], x[1], x[3]), [x[1], x[3]], [v[2]]),              # q
+        ("v_add_f32 v%d, v%d, v%d" % (v[1], E, v[2]), [E, v[2]], [v[1]]),                          # v1 = p + q
+        ("v_sub_f32 v%d, v%d, v%d" % (v[2], E, v[2]), [E, v[2]], [v[2]]),                          # v2 = p - q
+        ("v_sub_f32 v%d, v%d, v%d" % (F, x[4], x[2]), [x[4], x[2]], [F]),                          # r
+        ("v_sub_f32 v%d, v%d, v%d" % (v[4], x[3], x[1]), [x[3], x[1]], [v[4]]),                    # s
+        ("v_fma_f32 v%d, 2.0, v%d, v%d" % (v[3], v[4], F), [v[4], F], [v[3]]),                     # v3
+        ("v_fma_f32 v%d, -2.0, v%d, v%d" % (v[4], v[4], F), [v[4], F], [v[4]]),                    # v4
+        ("v_fma_f32 v%d, -%s, v%d, v%d" % (v[5], five, x[3], x[5]), [x[3], x[5]], [v[5]]),
+        ("v_fma_f32 v%d, 4.0, v%d, v%d" % (v[5], x[1], v[5]), [x[1], v[5]], [v[5]]),               # v5
+    ]
+    return ops
+
+
+def border_fixup(em, s):
+    """Tiles on the left / right image border fetch their rows in 16-byte pieces like every other tile, so the halo column
+    outside the image holds the neighbouring row's data (or 0 where the piece fell outside the buffer): the lanes whose
+    patch contains such columns replace them here, in registers, before the column pass -- by 0 (zero padding: every
+    column outside the image) or by the mirrored column (reflect padding: column -1 <- 1, column W <- W - 2; columns
+    beyond W only feed outputs that are never stored).  %[fixmask]: bit j = column j of this lane's patch is replaced.
+    Skipped (one scalar branch) for tiles that need nothing."""
+    regs = [treg(s, r, j) for r in range(6) for j in range(6)]
+    em.need(regs)                                              # (the wait must not sit inside the skipped block)
+    A = TMP[0]
+    em.raw("s_bitcmp1_b32 %[s_rflags], 1")
+    em.raw("s_cbranch_scc0 5f")
+    em.raw("s_bitcmp1_b32 %[s_rflags], 2")
+    em.raw("s_cbranch_scc1 4f")
+    for j in range(6):                                         # zero padding
+        em.raw("v_and_b32 v%d, %d, %%[fixmask]" % (A, 1 << j))
+        em.raw("v_cmp_ne_u32 vcc, 0, v%d" % A)
+        for r in range(6):
+            em.raw("v_cndmask_b32 v%d, v%d, 0, vcc" % (treg(s, r, j), treg(s, r, j)))
+    em.raw("s_branch 5f")
+    em.raw("4:")
+    for j in (5, 4, 3, 2, 0):                                  # reflect padding
+        em.raw("v_and_b32 v%d, %d, %%[fixmask]" % (A, 1 << j))
+        em.raw("v_cmp_ne_u32 vcc, 0, v%d" % A)
+        for r in range(6):
+            em.raw("v_cndmask_b32 v%d, v%d, v%d, vcc" % (treg(s, r, j), treg(s, r, j), treg(s, r, 2 if j == 0 else j - 2)))
+    em.raw("5:")
+
+
+def patch_reads(em, s):
+    for r in range(6):
+        em.ds_read(128, treg(s, r, 0), PADDR, r * ROWP * 4)
+        em.ds_read(64, treg(s, r, 4), PADDR, r * ROWP * 4 + 16)
+
+
+def weight_read(em, h, g):
+    em.ds_read(128, UBASE + 4 * (9 * h + g), WADDR, (g * BN + h * 16) * 16)
+
+
+def addr_setup(em):
+    em.raw("v_add_u32 v%d, %%[s_rd], %%[pa0]" % PADDR)
+    em.raw("v_add_u32 v%d, %%[s_rd], %%[wa0]" % WADDR)
+
+
+def dma_piece(em, kind, t):
+    """One 1 KiB LDS-DMA request of chunk c+4: input piece t (0..4) or weight piece t (0..4) of this wave."""
+    if kind == "in":
+        em.raw("s_add_i32 m0, %%[s_dma], %d" % (4096 * t))
+        em.raw("s_nop 0")
+        em.raw("buffer_load_dwordx4 %%[voff%d], %%[rin], 0 offen lds" % t)
+    else:
+        if t == 4:
+            em.raw("s_cmp_lt_u32 %[s_wave], 2")               # weight pieces 16, 17 exist for waves 0, 1 only
+            em.raw("s_cbranch_scc0 1f")
+        em.raw("s_add_i32 m0, %%[s_dma], %d" % (IN_FLOATS * 4 + 4096 * t))
+        em.raw("s_nop 0")
+        em.raw("buffer_load_dwordx4 %%[wvoff], %%[rw], %%[s_w%d] offen lds" % t)
+        if t == 4:
+            em.raw("1:")
+
+
+def entry_wait(em, chunks_in_flight):
+    """Own requests of the chunk about to be read have landed once only those of the `chunks_in_flight` younger chunks
+    are outstanding (waves 0, 1 issue 10 per chunk, waves 2, 3 nine); then the workgroup barrier publishes everyone's."""
+    em.raw("s_cmp_lt_u32 %[s_wave], 2")
+    em.raw("s_cbranch_scc1 2f")
+    em.raw("s_waitcnt vmcnt(%d)" % (9 * chunks_in_flight))
+    em.raw("s_branch 3f")
+    em.raw("2:")
+    em.raw("s_waitcnt vmcnt(%d)" % (10 * chunks_in_flight))
+    em.raw("3:")
+    em.raw("s_waitcnt lgkmcnt(0)")                             # (this wave's reads of the slot the DMA is about to reuse)
+    em.pending = []
+    em.raw("s_barrier")
+
+
+def gen_prime():
+    """Before the first chunk: chunk 0 has landed -> patch set 0 and the weights into registers, column pass, row 0."""
+    em = Emitter()
+    five = "%[s_five]"
+    addr_setup(em)
+    entry_wait(em, 3)
+    patch_reads(em, 0)
+    for h in range(2):
+        for g in range(NGRP):
+            weight_read(em, h, g)
+    border_fixup(em, 0)
+    for j in range(6):
+        for text, rd, wr in column_pass_ops(0, j, five):
+            em.valu(text, rd, wr)
+    for text, rd, wr in row_pass_ops(0, 0, VBUF[0], five):
+        em.valu(text, rd, wr)
+    em.raw("s_waitcnt lgkmcnt(0)")
+    return em.lines, []
+
+
+def mfma_order():
+    """(row i, column j, half h) in issue order: 12 per row of positions."""
+    return [(i, j, h) for i in range(6) for j in range(6) for h in range(2)]
+
+
+def gen_body(P, pending_in):
+    cur, nxt = P, 1 - P
+    five = "%[s_five]"
+    em = Emitter(pending_in)
+    order = mfma_order()
+    # last use (gap index) of every weight group / half
+    last_use = {}
+    for m, (i, j, h) in enumerate(order):
+        last_use[(h, (6 * i + j) // 4)] = m
+    # ---- work lists, each entry (earliest gap, callable) ----
+    sched = {g: [] for g in range(72)}
+
+    def at(gap, fn, cost):
+        sched[gap].append((fn, cost))
+
+    # patch reads of chunk c+1: gaps 1..6, two per gap (behind the barrier that follows MFMA 0)
+    k = 0
+    for r in range(6):
+        at(1 + k // 2, (lambda r=r: em.ds_read(128, treg(nxt, r, 0), PADDR, r * ROWP * 4)), 1)
+        k += 1
+        at(1 + k // 2, (lambda r=r: em.ds_read(64, treg(nxt, r, 4), PADDR, r * ROWP * 4 + 16)), 1)
+        k += 1
+    # weight reloads: one per gap from the gap after the last use (never beside the patch reads' gaps 1..6)
+    busy = {g: 0 for g in range(80)}
+    for g in range(1, 7):
+        busy[g] = 2
+    wl = sorted(last_use.items(), key=lambda kv: kv[1])
+    tail = []
+    for (h, g), m in wl:
+        gap = m
+        while gap < 72 and busy[gap] >= 1:
+            gap += 1
+        if gap >= 72:
+            tail.append((h, g))
+        else:
+            busy[gap] += 1
+            at(gap, (lambda h=h, g=g: weight_read(em, h, g)), 1)
+    # row passes of chunk c: row i+1 during the first six gaps of row i
+    for i in range(5):
+        ops = row_pass_ops(cur, i + 1, VBUF[(i + 1) % 2], five)
+        for n, (text, rd, wr) in enumerate(ops):
+            at(12 * i + n // 2, (lambda text=text, rd=rd, wr=wr: em.valu(text, rd, wr)), 1)
+    at(13, (lambda: border_fixup(em, nxt)), 2)
+    # column pass of chunk c+1: columns 0..5, two operations per gap from gap 14
+    n = 0
+    for j in range(6):
+        for text, rd, wr in column_pass_ops(nxt, j, five):
+            at(14 + n // 2, (lambda text=text, rd=rd, wr=wr: em.valu(text, rd, wr)), 1)
+            n += 1
+    assert 14 + (n - 1) // 2 <= 59
+    # row 0 of chunk c+1 into buffer 0 (free after row 4's MFMAs: gaps 48..59)
+    for n, (text, rd, wr) in enumerate(row_pass_ops(nxt, 0, VBUF[0], five)):
+        at(60 + n // 2, (lambda text=text, rd=rd, wr=wr: em.valu(text, rd, wr)), 1)
+    # DMA requests of chunk c+4
+    dma_gaps = [8, 13, 20, 25, 32, 37, 44, 49, 56, 66]
+    kinds = [("in", 0), ("w", 0), ("in", 1), ("w", 1), ("in", 2), ("w", 2), ("in", 3), ("w", 3), ("in", 4), ("w", 4)]
+    for gap, (kind, t) in zip(dma_gaps, kinds):
+        at(gap, (lambda kind=kind, t=t: dma_piece(em, kind, t)), 6)
+
+    # ---- emit ----
+    addr_setup(em)
+    for m, (i, j, h) in enumerate(order):
+        em.mfma(h, 6 * i + j, VBUF[i % 2] + j)
+        if m == 0:
+            entry_wait(em, 2)
+        for fn, _ in sched[m]:
+            fn()
+    for h, g in tail:
+        weight_read(em, h, g)
+    return em.lines, [sorted(p) for p in em.pending]
+
+
+def c_string(lines):
+    return "\n".join('    "%s\\n\\t"' % ln for ln in lines)
+
+
+def operands_macro(kind):
+    """Operand list of one statement: ST = the state struct (see vfi_conv_winograd4m.hip).  kind: "prime", 0 / 1 (body of
+    that parity) or "drain".  Only what a statement really reads is an input and only what the NEXT statement needs is
+    live afterwards: the patch set a body consumes is input-only, the set it fills output-only, so that set's registers
+    (and the second V row, the temporaries) are free for the compiler between the statements (item epilogue)."""
+    outs, ins = [], []
+    for k in range(72):
+        h, p = divmod(k, 36)
+        outs.append('"+{%s}"(ST.acc[%d])' % (acc_name(h, p), k))
+    if kind == "drain":
+        return outs, ins
+
+    def tset(s, fmt_lo, fmt_hi, dst):
+        for r in range(6):
+            b = treg(s, r, 0)
+            dst.append(fmt_lo % (b, b + 3, s, r))
+            dst.append(fmt_hi % (b + 4, b + 5, s, r))
+
+    if kind == "prime":
+        tset(0, '"=&{v[%d:%d]}"(ST.t_lo[%d][%d])', '"=&{v[%d:%d]}"(ST.t_hi[%d][%d])', outs)
+        uc = '"=&{v[%d:%d]}"(ST.u[%d])'
+        vc = ['"=&{v[%d:%d]}"(ST.vb[%d])'] * 3
+    else:
+        tset(1 - kind, '"=&{v[%d:%d]}"(ST.t_lo[%d][%d])', '"=&{v[%d:%d]}"(ST.t_hi[%d][%d])', outs)
+        tset(kind, '"{v[%d:%d]}"(ST.t_lo[%d][%d])', '"{v[%d:%d]}"(ST.t_hi[%d][%d])', ins)
+        uc = '"+{v[%d:%d]}"(ST.u[%d])'
+        # V row buffer 0 = v212..217 carries row 0 into the next statement; it spans vb[0] and half of vb[1]
+        vc = ['"+{v[%d:%d]}"(ST.vb[%d])', '"+{v[%d:%d]}"(ST.vb[%d])', '"=&{v[%d:%d]}"(ST.vb[%d])']
+    for k in range(18):
+        outs.append(uc % (UBASE + 4 * k, UBASE + 4 * k + 3, k))
+    for k in range(3):
+        outs.append(vc[k] % (VBUF[0] + 4 * k, VBUF[0] + 4 * k + 3, k))
+    for k, r in enumerate(TMP + RTMP + [PADDR, WADDR]):
+        outs.append('"=&{v%d}"(ST.tmp[%d])' % (r, k))
+    ins += ['[pa0] "v"(ST.pa0)', '[wa0] "v"(ST.wa0)', '[fixmask] "v"(ST.fixmask)', '[s_rd] "s"(ST.s_rd)', '[s_rflags] "s"(ST.s_rflags)',
+            '[s_wave] "s"(ST.s_wave)', '[s_five] "s"(ST.s_five)']
+    if kind != "prime":
+        ins += ['[wvoff] "v"(ST.wvoff)'] + ['[voff%d] "v"(ST.voff[%d])' % (t, t) for t in range(5)]
+        ins += ['[rin] "s"(ST.rin)', '[rw] "s"(ST.rw)', '[s_dma] "s"(ST.s_dma)'] + ['[s_w%d] "s"(ST.s_w[%d])' % (t, t) for t in range(5)]
+    return outs, ins
+
+
+def main(out_path):
+    prime, _ = gen_prime()
+    # the reads left in flight at the end of a body are the reads pending at the start of the next one: iterate to the fixed point
+    pend = {0: [], 1: []}
+    for _ in range(3):
+        b0, t0 = gen_body(0, pend[0])
+        b1, t1 = gen_body(1, pend[1])
+        pend = {0: t1, 1: t0}
+    b0, t0 = gen_body(0, pend[0])
+    b1, t1 = gen_body(1, pend[1])
+    assert t1 == pend[0] and t0 == pend[1], "tail reads did not reach a fixed point"
+    n_mfma = sum(1 for ln in b0 if ln.startswith("v_mfma"))
+    n_valu = sum(1 for ln in b0 if ln.startswith(("v_fma", "v_add_f32", "v_sub")))
+    assert n_mfma == 72 and n_valu == 144, (n_mfma, n_valu)
+    with open(out_path, "w") as f:
+        f.write("// GENERATED by tools/gen_wino4m.py -- do not edit.  Chunk body of conv3x3_winograd4m_kernel (vfi_conv_winograd4m.hip).\n")
+        f.write("// per body: %d MFMAs, %d transform operations, %d LDS reads, 10 LDS-DMA requests\n" %
+                (n_mfma, n_valu, sum(1 for ln in b0 if ln.startswith("ds_read"))))
+        f.write("#pragma once\n")
+        f.write("#define W4M_FIRST_FIXED_VGPR %d\n" % FIRST_FREE)
+        f.write("#define W4M_ASM_PRIME \\\n" + c_string(prime).replace("\n", " \\\n") + "\n")
+        f.write("// before the epilogue reads the accumulators: the last MFMAs (8 passes) must have written them back\n")
+        f.write('#define W4M_ASM_DRAIN "s_nop 7\\n\\ts_nop 7\\n\\t"\n')
+        f.write("#define W4M_ASM_BODY0 \\\n" + c_string(b0).replace("\n", " \\\n") + "\n")
+        f.write("#define W4M_ASM_BODY1 \\\n" + c_string(b1).replace("\n", " \\\n") + "\n")
+        for kind, tag in (("prime", "PRIME"), (0, "BODY0"), (1, "BODY1"), ("drain", "DRAIN")):
+            outs, ins = operands_macro(kind)
+            f.write("#define W4M_OPERANDS_%s(ST) \\\n    : " % tag + ", \\\n      ".join(outs) + " \\\n    : " + ", \\\n      ".join(ins) + "\n")
+    return prime, b0, b1
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    default = os.path.join(here, "..", "fusion-method-for-video-frame-interpolation_amd", "csrc", "vfi_conv_winograd4m_body.h")
+    main(sys.argv[1] if len(sys.argv) > 1 else default)
