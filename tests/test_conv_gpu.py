@@ -100,6 +100,44 @@ def test_f4x4_kernel_on_small_and_ragged_shapes(device):
     assert m and float(m.group(1)) <= 1e-4, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,pad,act,variant", [
+    (1, 64, 64, 272, 1920, "zeros", "relu", "plain"),       # the 1080p U-Net / PhaseNet shape class: 16 chunks per item
+    (3, 64, 64, 100, 1920, "reflect", "elu", "residual"),   # PhaseNet block with its residual, ragged tile rows
+    (1, 28, 25, 544, 1920, "zeros", None, "plain"),         # head layer: 7 chunks (odd: both body parities end an item), Cout tail
+    (2, 32, 64, 256, 1024, "zeros", "relu", "pool"),        # pooled second output
+    (1, 16, 96, 512, 2048, "reflect", "tanh", "plain"),     # three channel blocks, 4 chunks: items shorter than the ring
+])
+def test_f4x4_m32_kernel_equals_m16_kernel_bit_for_bit(n, cin, cout, h, w, pad, act, variant, device, monkeypatch):
+    """conv3x3_winograd4m_kernel (one wave per SIMD, 32 output channels per wave, hand-scheduled chunk body) performs the
+    arithmetic of conv3x3_winograd4_kernel in the same order: where the row length is a multiple of the 64-column tile the
+    two must agree bit for bit (VFI_CONV_WINOGRAD4M selects per call).  Also against float64 with the F(4x4) tolerance."""
+    from vfi_amd import _lib
+    g = torch.Generator().manual_seed(cin * 7 + cout + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wgt = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    res = torch.randn((n, cout, h, w), generator=g) if variant == "residual" else None
+    pc = ops.PackedConv(wgt, b, device=device)
+    xd, rd = x.to(device), None if res is None else res.to(device)
+
+    def run():
+        if variant == "pool":
+            return ops.conv2d_pool2(xd, pc, False, pad, act)
+        return (ops.conv2d(xd, pc, pad, act, residual=rd),)
+
+    assert _lib.lib().vfi_conv2d_algo(n, cin, h, w, cout, 3, int(res is not None), int(variant == "pool"), ops.ACT[act]) == 2, "shape must take the F(4x4) path"
+    monkeypatch.setenv("VFI_CONV_WINOGRAD4M", "0")
+    old = [t.clone() for t in run()]
+    monkeypatch.setenv("VFI_CONV_WINOGRAD4M", "1")
+    new = run()
+    torch.cuda.synchronize()
+    for a_, b_ in zip(old, new):
+        assert torch.equal(a_, b_), (a_ - b_).abs().max().item()
+    ref = _ref(x.double(), wgt.double(), b.double(), 3, pad, act, res=None if res is None else res.double())
+    err = (new[0].cpu().double() - ref).abs()
+    assert err.max().item() <= 1e-4 and err.pow(2).mean().sqrt().item() <= 5e-6, (err.max().item(), err.pow(2).mean().sqrt().item())
+
+
 def test_large_conv_with_residual_matches_torch_cpu(device):
     # the residual variant of the F(4x4) Winograd kernel (PhaseNet blocks at full resolution): act(conv + b) + residual
     n, cin, cout, h, w = 2, 16, 64, 270, 1920

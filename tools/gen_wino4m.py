@@ -27,14 +27,16 @@ BUF_BYTES = (IN_FLOATS + W_FLOATS) * 4
 NBUF = 4
 
 # ---- register map (VGPR numbers) -------------------------------------------------------------------------------------
-TMP = [60, 61, 62, 63]          # column-pass temporaries
-RTMP = [64, 65]                 # row-pass temporaries
+TMP = [58, 60, 62, 64]          # transform temporaries: four even-aligned register PAIRS (v58..v65)
+RTMP = [64, 65]                 # (unpacked variant: row-pass temporaries)
 PADDR, WADDR = 66, 67           # LDS byte addresses of this chunk's reads (patch / weights)
 TSET = [68, 104]                # patch sets A, B: row r at base + 6 r (6 registers)
 UBASE = 140                     # u[h][g] (4 positions of group g, 16-channel half h) at UBASE + 4 (9 h + g)
 VBUF = [212, 218]               # V rows: buffer 0 / 1 (6 registers each)
 ACCV = 224                      # accumulators 64..71 (VGPRs); 0..63 are a[0:255]
-FIRST_FREE = 60                 # the compiler keeps to v0 .. v59 inside the chunk loop
+FIRST_FREE = 58                 # the compiler keeps to v0 .. v57 inside the chunk loop
+# ---- pinned SGPRs: the request cursor lives in the body (its per-chunk arithmetic runs in the MFMAs' shadow) ----------
+S_RIN, S_RW, S_DMA, S_RD = 76, 80, 84, 85      # s[76:79] input descriptor, s[80:83] weight descriptor, LDS slot of the requests / reads
 
 
 def treg(s, r, j):
@@ -52,6 +54,11 @@ def acc_name(h, p):
     return "v[%d:%d]" % (ACCV + 4 * (k - 64), ACCV + 4 * (k - 64) + 3)
 
 
+# Elimination builds (development aid, timing only -- results are garbage): W4M_ELIM=dma,barrier,vmcnt,mfma,valu,lds drops
+# that class of instruction from the bodies.
+ELIM = set(filter(None, os.environ.get("W4M_ELIM", "").split(",")))
+
+
 class Emitter:
     """Instruction list with the LDS-read bookkeeping: a load's destination registers are pending until a
     `s_waitcnt lgkmcnt(k)` that retires it; k = number of LDS operations issued after it (in-order return)."""
@@ -62,6 +69,11 @@ class Emitter:
         self.lds_ops = 0
 
     def raw(self, text):
+        op = text.split()[0]
+        if ("dma" in ELIM and (op.startswith("buffer_load") or "m0" in text)) or ("barrier" in ELIM and op == "s_barrier") or \
+           ("vmcnt" in ELIM and "vmcnt" in text) or ("mfma" in ELIM and op.startswith("v_mfma")) or \
+           ("valu" in ELIM and op in ("v_fma_f32", "v_add_f32", "v_sub_f32", "v_pk_fma_f32", "v_pk_add_f32")) or ("lds" in ELIM and op.startswith("ds_read")):
+            return
         self.lines.append(text)
 
     def need(self, regs):
@@ -103,7 +115,7 @@ def column_pass_ops(s, j, five):
     """In place on column j of patch set s: 12 operations, 4 temporaries, no moves (the order matters: an output
     overwrites an input only after that input's last use)."""
     x = [treg(s, r, j) for r in range(6)]
-    A, B, C, D = TMP
+    A, B, C, D = 60, 61, 62, 63
     ops = [
         ("v_fma_f32 v%d, -%s, v%d, v%d" % (C, five, x[2], x[4]), [x[2], x[4]], [C]),
         ("v_fma_f32 v%d, 4.0, v%d, v%d" % (x[0], x[0], C), [x[0], C], [x[0]]),                     # t0
@@ -143,6 +155,75 @@ def row_pass_ops(s, i, vb, five):
     return ops
 
 
+# Packed forms (v_pk_fma_f32 / v_pk_add_f32: two fp32 lanes per instruction).  On gfx950 an fp32 MFMA and the vector ALU
+# do not overlap -- measured: a body with only its 72 MFMAs takes 2392 cycles, with the 144 scalar transform operations
+# spread between them 3471, grouped 3056 -- so every transform INSTRUCTION is paid in full and halving their number is the
+# lever.  Same fused operations, same operands as the scalar forms: bit-identical results.
+PK = os.environ.get("W4M_PK", "1") != "0"
+VMAP = [0, 2, 3, 4, 5, 1]        # packed row pass: V row register of column j (pairs (v0,v5), (v1,v2), (v3,v4))
+
+
+def vreg(buf, j):
+    return buf + (VMAP[j] if PK else j)
+
+
+def pair(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def column_pass_pk(s, j):
+    """Columns j, j+1 (j even) of patch set s, in place: the 12 operations of column_pass_ops on register pairs."""
+    x = [treg(s, r, j) for r in range(6)]
+    A, B, C, D = TMP
+    P = pair
+    two = lambda r: [r, r + 1]
+    ops = [
+        ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(C), P(x[2]), P(x[4])), two(x[2]) + two(x[4]), two(C)),
+        ("v_pk_fma_f32 %s, %%[k4], %s, %s" % (P(x[0]), P(x[0]), P(C)), two(x[0]) + two(C), two(x[0])),
+        ("v_pk_fma_f32 %s, %%[k4], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(A), P(x[2]), P(x[4])), two(x[2]) + two(x[4]), two(A)),
+        ("v_pk_fma_f32 %s, %%[k4], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(B), P(x[1]), P(x[3])), two(x[1]) + two(x[3]), two(B)),
+        ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(C), P(x[4]), P(x[2])), two(x[4]) + two(x[2]), two(C)),
+        ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(D), P(x[3]), P(x[1])), two(x[3]) + two(x[1]), two(D)),
+        ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(x[5]), P(x[3]), P(x[5])), two(x[3]) + two(x[5]), two(x[5])),
+        ("v_pk_fma_f32 %s, %%[k4], %s, %s" % (P(x[5]), P(x[1]), P(x[5])), two(x[1]) + two(x[5]), two(x[5])),
+        ("v_pk_add_f32 %s, %s, %s" % (P(x[1]), P(A), P(B)), two(A) + two(B), two(x[1])),
+        ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(x[2]), P(A), P(B)), two(A) + two(B), two(x[2])),
+        ("v_pk_fma_f32 %s, %%[k2], %s, %s" % (P(x[3]), P(D), P(C)), two(D) + two(C), two(x[3])),
+        ("v_pk_fma_f32 %s, %%[k2], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(x[4]), P(D), P(C)), two(D) + two(C), two(x[4])),
+    ]
+    return ops
+
+
+def row_pass_pk(s, i, vb):
+    """Row i of patch set s -> V row in buffer vb as the pairs (v0,v5), (v1,v2), (v3,v4): 6 packed operations."""
+    x01, x23, x45 = treg(s, i, 0), treg(s, i, 2), treg(s, i, 4)
+    I, PR, QS, _ = TMP
+    O0, O1, O2 = vb, vb + 2, vb + 4
+    P = pair
+    two = lambda r: [r, r + 1]
+    ops = [
+        ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(I), P(x23), P(x45)), two(x23) + two(x45), two(I)),          # (-5 x2 + x4, -5 x3 + x5)
+        ("v_pk_fma_f32 %s, %%[k4], %s, %s" % (P(O0), P(x01), P(I)), two(x01) + two(I), two(O0)),                                           # (v0, v5)
+        ("v_pk_fma_f32 %s, %%[k41], %s, %s op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(PR), P(x23), P(x45)),
+         two(x23) + two(x45), two(PR)),                                                                                                    # (p, r) = (x4 - 4 x2, x4 - x2)
+        ("v_pk_fma_f32 %s, %%[k41], %s, %s op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(QS), P(x01), P(x23)),
+         two(x01) + two(x23), two(QS)),                                                                                                    # (q, s) = (x3 - 4 x1, x3 - x1)
+        ("v_pk_add_f32 %s, %s, %s op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" % (P(O1), P(PR), P(QS)), two(PR) + two(QS), two(O1)),         # (v1, v2) = (p + q, p - q)
+        ("v_pk_fma_f32 %s, %%[k2], %s, %s op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_hi:[1,0,0]" % (P(O2), P(QS), P(PR)), two(QS) + two(PR), two(O2)),   # (v3, v4) = (2 s + r, -2 s + r)
+    ]
+    return ops
+
+
+def column_pass_all(s, five):
+    if PK:
+        return [op for j in (0, 2, 4) for op in column_pass_pk(s, j)]
+    return [op for j in range(6) for op in column_pass_ops(s, j, five)]
+
+
+def row_pass_any(s, i, vb, five):
+    return row_pass_pk(s, i, vb) if PK else row_pass_ops(s, i, vb, five)
+
+
 def border_fixup(em, s):
     """Tiles on the left / right image border fetch their rows in 16-byte pieces like every other tile, so the halo column
     outside the image holds the neighbouring row's data (or 0 where the piece fell outside the buffer): the lanes whose
@@ -152,9 +233,18 @@ def border_fixup(em, s):
     Skipped (one scalar branch) for tiles that need nothing."""
     regs = [treg(s, r, j) for r in range(6) for j in range(6)]
     em.need(regs)                                              # (the wait must not sit inside the skipped block)
-    A = TMP[0]
+    A = 60
     em.raw("s_bitcmp1_b32 %[s_rflags], 1")
     em.raw("s_cbranch_scc0 5f")
+    # One piece of a chunk cannot be fetched where it belongs: columns -1..2 of image row 0 of the chunk's FIRST channel in
+    # a tile at the left border start 4 bytes before the buffer, and a 16-byte request whose first dword lies before the
+    # base returns zeros for all four (measured, tools/probes/buffer_oob.hip).  The kernel fetches columns 0..3 there
+    # instead; the one lane and patch row that read them (%[fixmask] bit 8 + row) move them up by one column.
+    for i in range(6):
+        em.raw("v_and_b32 v%d, %d, %%[fixmask]" % (A, 256 << i))
+        em.raw("v_cmp_ne_u32 vcc, 0, v%d" % A)
+        for j in (3, 2, 1):
+            em.raw("v_cndmask_b32 v%d, v%d, v%d, vcc" % (treg(s, i, j), treg(s, i, j), treg(s, i, j - 1)))
     em.raw("s_bitcmp1_b32 %[s_rflags], 2")
     em.raw("s_cbranch_scc1 4f")
     for j in range(6):                                         # zero padding
@@ -183,23 +273,49 @@ def weight_read(em, h, g):
 
 
 def addr_setup(em):
-    em.raw("v_add_u32 v%d, %%[s_rd], %%[pa0]" % PADDR)
-    em.raw("v_add_u32 v%d, %%[s_rd], %%[wa0]" % WADDR)
+    em.raw("v_add_u32 v%d, s%d, %%[pa0]" % (PADDR, S_RD))
+    em.raw("v_add_u32 v%d, s%d, %%[wa0]" % (WADDR, S_RD))
+
+
+def read_cursor_step(em):
+    """The ring slot the NEXT statement reads from."""
+    em.raw("s_add_u32 s%d, s%d, %d" % (S_RD, S_RD, BUF_BYTES))
+    em.raw("s_cmp_ge_u32 s%d, %d" % (S_RD, NBUF * BUF_BYTES))
+    em.raw("s_cbranch_scc0 7f")
+    em.raw("s_mov_b32 s%d, 0" % S_RD)
+    em.raw("7:")
+
+
+def request_cursor_step(em):
+    """Past the chunk just requested: descriptor bases move on by one chunk, the remaining input bytes shrink (saturating:
+    the channel tail of the last chunk and everything past the item read as 0), next ring slot.  At an item boundary the
+    kernel overwrites all of it after the statement."""
+    em.raw("s_add_u32 s%d, s%d, %%[s_inc]" % (S_RIN, S_RIN))
+    em.raw("s_addc_u32 s%d, s%d, 0" % (S_RIN + 1, S_RIN + 1))
+    em.raw("s_sub_u32 s%d, s%d, %%[s_inc]" % (S_RIN + 2, S_RIN + 2))
+    em.raw("s_cselect_b32 s%d, 0, s%d" % (S_RIN + 2, S_RIN + 2))
+    em.raw("s_add_u32 s%d, s%d, %%[s_winc]" % (S_RW, S_RW))
+    em.raw("s_addc_u32 s%d, s%d, 0" % (S_RW + 1, S_RW + 1))
+    em.raw("s_add_u32 s%d, s%d, %d" % (S_DMA, S_DMA, BUF_BYTES))
+    em.raw("s_cmp_ge_u32 s%d, %%[s_dma_end]" % S_DMA)
+    em.raw("s_cbranch_scc0 6f")
+    em.raw("s_sub_u32 s%d, s%d, %d" % (S_DMA, S_DMA, NBUF * BUF_BYTES))
+    em.raw("6:")
 
 
 def dma_piece(em, kind, t):
     """One 1 KiB LDS-DMA request of chunk c+4: input piece t (0..4) or weight piece t (0..4) of this wave."""
     if kind == "in":
-        em.raw("s_add_i32 m0, %%[s_dma], %d" % (4096 * t))
+        em.raw("s_add_i32 m0, s%d, %d" % (S_DMA, 4096 * t))
         em.raw("s_nop 0")
-        em.raw("buffer_load_dwordx4 %%[voff%d], %%[rin], 0 offen lds" % t)
+        em.raw("buffer_load_dwordx4 %%[voff%d], s[%d:%d], 0 offen lds" % (t, S_RIN, S_RIN + 3))
     else:
         if t == 4:
             em.raw("s_cmp_lt_u32 %[s_wave], 2")               # weight pieces 16, 17 exist for waves 0, 1 only
             em.raw("s_cbranch_scc0 1f")
-        em.raw("s_add_i32 m0, %%[s_dma], %d" % (IN_FLOATS * 4 + 4096 * t))
+        em.raw("s_add_i32 m0, s%d, %d" % (S_DMA, IN_FLOATS * 4 + 4096 * t))
         em.raw("s_nop 0")
-        em.raw("buffer_load_dwordx4 %%[wvoff], %%[rw], %%[s_w%d] offen lds" % t)
+        em.raw("buffer_load_dwordx4 %%[wvoff], s[%d:%d], %%[s_w%d] offen lds" % (S_RW, S_RW + 3, t))
         if t == 4:
             em.raw("1:")
 
@@ -230,12 +346,12 @@ def gen_prime():
         for g in range(NGRP):
             weight_read(em, h, g)
     border_fixup(em, 0)
-    for j in range(6):
-        for text, rd, wr in column_pass_ops(0, j, five):
-            em.valu(text, rd, wr)
-    for text, rd, wr in row_pass_ops(0, 0, VBUF[0], five):
+    for text, rd, wr in column_pass_all(0, five):
+        em.valu(text, rd, wr)
+    for text, rd, wr in row_pass_any(0, 0, VBUF[0], five):
         em.valu(text, rd, wr)
     em.raw("s_waitcnt lgkmcnt(0)")
+    read_cursor_step(em)
     return em.lines, []
 
 
@@ -256,7 +372,11 @@ def gen_body(P, pending_in):
     # ---- work lists, each entry (earliest gap, callable) ----
     sched = {g: [] for g in range(72)}
 
-    def at(gap, fn, cost):
+    cluster = int(os.environ.get("W4M_CLUSTER", "6"))      # transform operations go in blocks behind every cluster-th MFMA (see PK above)
+
+    def at(gap, fn, cost, valu=False):
+        if valu and cluster > 1:
+            gap = min(71, gap // cluster * cluster + cluster - 1)
         sched[gap].append((fn, cost))
 
     # patch reads of chunk c+1: gaps 1..6, two per gap (behind the barrier that follows MFMA 0)
@@ -282,31 +402,43 @@ def gen_body(P, pending_in):
             busy[gap] += 1
             at(gap, (lambda h=h, g=g: weight_read(em, h, g)), 1)
     # row passes of chunk c: row i+1 during the first six gaps of row i
-    for i in range(5):
-        ops = row_pass_ops(cur, i + 1, VBUF[(i + 1) % 2], five)
-        for n, (text, rd, wr) in enumerate(ops):
-            at(12 * i + n // 2, (lambda text=text, rd=rd, wr=wr: em.valu(text, rd, wr)), 1)
-    at(13, (lambda: border_fixup(em, nxt)), 2)
-    # column pass of chunk c+1: columns 0..5, two operations per gap from gap 14
-    n = 0
-    for j in range(6):
-        for text, rd, wr in column_pass_ops(nxt, j, five):
-            at(14 + n // 2, (lambda text=text, rd=rd, wr=wr: em.valu(text, rd, wr)), 1)
-            n += 1
-    assert 14 + (n - 1) // 2 <= 59
-    # row 0 of chunk c+1 into buffer 0 (free after row 4's MFMAs: gaps 48..59)
-    for n, (text, rd, wr) in enumerate(row_pass_ops(nxt, 0, VBUF[0], five)):
-        at(60 + n // 2, (lambda text=text, rd=rd, wr=wr: em.valu(text, rd, wr)), 1)
+    valu = lambda text, rd, wr: (lambda: em.valu(text, rd, wr))
+    if PK:
+        # whole passes as blocks (they share the temporaries): row i+1 in the middle of row i's MFMAs, a pair of columns of the
+        # next chunk's column pass every 12 MFMAs behind the border fix-up, the next chunk's row 0 near the end
+        for i in range(5):
+            for text, rd, wr in row_pass_pk(cur, i + 1, VBUF[(i + 1) % 2]):
+                at(12 * i + 6, valu(text, rd, wr), 1)
+        at(13, (lambda: border_fixup(em, nxt)), 2)
+        for jj in range(3):
+            for text, rd, wr in column_pass_pk(nxt, 2 * jj):
+                at(16 + 12 * jj, valu(text, rd, wr), 1)
+        for text, rd, wr in row_pass_pk(nxt, 0, VBUF[0]):
+            at(64, valu(text, rd, wr), 1)
+    else:
+        for i in range(5):
+            for n, (text, rd, wr) in enumerate(row_pass_ops(cur, i + 1, VBUF[(i + 1) % 2], five)):
+                at(12 * i + n // 2, valu(text, rd, wr), 1, True)
+        at(13, (lambda: border_fixup(em, nxt)), 2)
+        n = 0
+        for j in range(6):
+            for text, rd, wr in column_pass_ops(nxt, j, five):
+                at(14 + n // 2, valu(text, rd, wr), 1, True)
+                n += 1
+        for n, (text, rd, wr) in enumerate(row_pass_ops(nxt, 0, VBUF[0], five)):
+            at(60 + n // 2, valu(text, rd, wr), 1, True)
     # DMA requests of chunk c+4
     dma_gaps = [8, 13, 20, 25, 32, 37, 44, 49, 56, 66]
     kinds = [("in", 0), ("w", 0), ("in", 1), ("w", 1), ("in", 2), ("w", 2), ("in", 3), ("w", 3), ("in", 4), ("w", 4)]
     for gap, (kind, t) in zip(dma_gaps, kinds):
         at(gap, (lambda kind=kind, t=t: dma_piece(em, kind, t)), 6)
+    at(68, (lambda: request_cursor_step(em)), 2)          # (after the last request that uses the descriptors / the slot)
+    at(30, (lambda: read_cursor_step(em)), 1)             # (after the statement's last use of the read slot: its address setup)
 
     # ---- emit ----
     addr_setup(em)
     for m, (i, j, h) in enumerate(order):
-        em.mfma(h, 6 * i + j, VBUF[i % 2] + j)
+        em.mfma(h, 6 * i + j, vreg(VBUF[i % 2], j))
         if m == 0:
             entry_wait(em, 2)
         for fn, _ in sched[m]:
@@ -329,7 +461,7 @@ def operands_macro(kind):
     for k in range(72):
         h, p = divmod(k, 36)
         outs.append('"+{%s}"(ST.acc[%d])' % (acc_name(h, p), k))
-    if kind == "drain":
+    if kind in ("drain", "zero"):
         return outs, ins
 
     def tset(s, fmt_lo, fmt_hi, dst):
@@ -352,13 +484,15 @@ def operands_macro(kind):
         outs.append(uc % (UBASE + 4 * k, UBASE + 4 * k + 3, k))
     for k in range(3):
         outs.append(vc[k] % (VBUF[0] + 4 * k, VBUF[0] + 4 * k + 3, k))
-    for k, r in enumerate(TMP + RTMP + [PADDR, WADDR]):
+    for k, r in enumerate(list(range(FIRST_FREE, PADDR)) + [PADDR, WADDR]):
         outs.append('"=&{v%d}"(ST.tmp[%d])' % (r, k))
-    ins += ['[pa0] "v"(ST.pa0)', '[wa0] "v"(ST.wa0)', '[fixmask] "v"(ST.fixmask)', '[s_rd] "s"(ST.s_rd)', '[s_rflags] "s"(ST.s_rflags)',
-            '[s_wave] "s"(ST.s_wave)', '[s_five] "s"(ST.s_five)']
+    outs.append('"+{s%d}"(ST.s_rd)' % S_RD)
+    ins += ['[pa0] "v"(ST.pa0)', '[wa0] "v"(ST.wa0)', '[fixmask] "v"(ST.fixmask)', '[s_rflags] "s"(ST.s_rflags)',
+            '[s_wave] "s"(ST.s_wave)', '[s_five] "s"(ST.s_five)', '[k4] "s"(ST.k4)', '[k5] "s"(ST.k5)', '[k2] "s"(ST.k2)', '[k41] "s"(ST.k41)']
     if kind != "prime":
+        outs += ['"+{s[%d:%d]}"(ST.rin)' % (S_RIN, S_RIN + 3), '"+{s[%d:%d]}"(ST.rw)' % (S_RW, S_RW + 3), '"+{s%d}"(ST.s_dma)' % S_DMA]
         ins += ['[wvoff] "v"(ST.wvoff)'] + ['[voff%d] "v"(ST.voff[%d])' % (t, t) for t in range(5)]
-        ins += ['[rin] "s"(ST.rin)', '[rw] "s"(ST.rw)', '[s_dma] "s"(ST.s_dma)'] + ['[s_w%d] "s"(ST.s_w[%d])' % (t, t) for t in range(5)]
+        ins += ['[s_inc] "s"(ST.s_inc)', '[s_winc] "s"(ST.s_winc)', '[s_dma_end] "s"(ST.s_dma_end)'] + ['[s_w%d] "s"(ST.s_w[%d])' % (t, t) for t in range(5)]
     return outs, ins
 
 
@@ -374,8 +508,8 @@ def main(out_path):
     b1, t1 = gen_body(1, pend[1])
     assert t1 == pend[0] and t0 == pend[1], "tail reads did not reach a fixed point"
     n_mfma = sum(1 for ln in b0 if ln.startswith("v_mfma"))
-    n_valu = sum(1 for ln in b0 if ln.startswith(("v_fma", "v_add_f32", "v_sub")))
-    assert n_mfma == 72 and n_valu == 144, (n_mfma, n_valu)
+    n_valu = sum(1 for ln in b0 if ln.startswith(("v_fma", "v_add_f32", "v_sub", "v_pk_")))
+    assert ELIM or (n_mfma == 72 and n_valu == (72 if PK else 144)), (n_mfma, n_valu)
     with open(out_path, "w") as f:
         f.write("// GENERATED by tools/gen_wino4m.py -- do not edit.  Chunk body of conv3x3_winograd4m_kernel (vfi_conv_winograd4m.hip).\n")
         f.write("// per body: %d MFMAs, %d transform operations, %d LDS reads, 10 LDS-DMA requests\n" %
@@ -385,9 +519,14 @@ def main(out_path):
         f.write("#define W4M_ASM_PRIME \\\n" + c_string(prime).replace("\n", " \\\n") + "\n")
         f.write("// before the epilogue reads the accumulators: the last MFMAs (8 passes) must have written them back\n")
         f.write('#define W4M_ASM_DRAIN "s_nop 7\\n\\ts_nop 7\\n\\t"\n')
+        zero = ["v_accvgpr_write_b32 a%d, 0" % n for n in range(256)] + ["v_mov_b32 v%d, 0" % (ACCV + n) for n in range(32)]
+        f.write("// after the epilogue has read them (its reads name the registers literally: the accumulators never become C++ values,\n"
+                "// or the compiler would copy all 288 into VGPRs)\n")
+        f.write("#define W4M_ACCV %d\n" % ACCV)
+        f.write("#define W4M_ASM_ZERO \\\n" + c_string(zero).replace("\n", " \\\n") + "\n")
         f.write("#define W4M_ASM_BODY0 \\\n" + c_string(b0).replace("\n", " \\\n") + "\n")
         f.write("#define W4M_ASM_BODY1 \\\n" + c_string(b1).replace("\n", " \\\n") + "\n")
-        for kind, tag in (("prime", "PRIME"), (0, "BODY0"), (1, "BODY1"), ("drain", "DRAIN")):
+        for kind, tag in (("prime", "PRIME"), (0, "BODY0"), (1, "BODY1"), ("drain", "DRAIN"), ("zero", "ZERO")):
             outs, ins = operands_macro(kind)
             f.write("#define W4M_OPERANDS_%s(ST) \\\n    : " % tag + ", \\\n      ".join(outs) + " \\\n    : " + ", \\\n      ".join(ins) + "\n")
     return prime, b0, b1

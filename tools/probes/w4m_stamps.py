@@ -1,0 +1,28 @@
+"""Probe: where a wave of conv3x3_winograd4m_kernel spends its cycles (library built with -DW4M_STAMPS as
+vfi_amd/libvfi_stamps.so: s_memtime around the body statements and the item epilogues)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+os.environ["VFI_HIP_LIBRARY"] = os.path.join(ROOT, "fusion-method-for-video-frame-interpolation_amd", "vfi_amd", "libvfi_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "stamps"))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "fusion-method-for-video-frame-interpolation_amd")]
+from vfi_amd import ops, _lib
+dev = torch.device("cuda:0")
+cases = [("pn.l7b 64->64 x3 1080p", 3, 64, 64, 1080, 1920, "reflect", "elu"), ("head 28->25 1088x1920", 1, 25, 25, 1088, 1920, "zeros", None)]
+for name, n, cin, cout, h, w, pad, act in cases:
+    x = torch.randn((n, cin, h, w), device=dev)
+    pc = ops.PackedConv(torch.randn((cout, cin, 3, 3)) / (cin * 9) ** 0.5, torch.zeros(cout), device=dev)
+    for _ in range(3):
+        ops.conv2d(x, pc, pad, act)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); ops.conv2d(x, pc, pad, act); e1.record(); torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * (256 * 4 * 8))()
+    assert _lib.lib().vfi_debug_w4m_stamps(buf, 256 * 4 * 8) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 4, 8).astype(np.float64)
+    body, between, epi, nb, ne, total = (a[..., k] for k in range(6))
+    ms = e0.elapsed_time(e1)
+    print(f"{name}: {ms:.3f} ms; per wave: total {total.mean():.0f} cycles -> clock {total.mean() / ms / 1e3:.0f} MHz (if the kernel fills the launch)")
+    print(f"  bodies {nb.mean():.0f} x {body.sum() / nb.sum():.0f} cycles; between bodies {between.sum() / nb.sum():.0f} cycles per body; "
+          f"epilogues {ne.mean():.1f} x {epi.sum() / ne.sum():.0f} cycles; unaccounted {(total - body - between - epi).mean():.0f}")
+    for wv in range(4):
+        print(f"  wave {wv}: body {body[:, wv].sum() / nb[:, wv].sum():.0f} between {between[:, wv].sum() / nb[:, wv].sum():.0f} epi {epi[:, wv].sum() / ne[:, wv].sum():.0f}")

@@ -29,6 +29,8 @@ class Wave:
         self.ops = {}
         self.trow = trow
         self.counts = {"mfma": 0, "valu": 0, "ds": 0, "dma": 0, "barrier": 0}
+        self.s = {}                                 # pinned scalar registers the text names literally
+        self.scc = False
 
     def reg(self, tok):
         """-> (file, first, count)"""
@@ -100,6 +102,29 @@ class Wave:
                 else:
                     res = s[0] - s[1]
                 self.v[d] = res.astype(np.float32)
+            elif op in ("v_pk_fma_f32", "v_pk_add_f32"):
+                self.counts["valu"] += 1
+                nsrc = 3 if op == "v_pk_fma_f32" else 2
+                body, *mods = re.split(r"\s+(?=op_sel|neg_)", rest)
+                toks = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", body)]
+                m = {"op_sel": [0] * nsrc, "op_sel_hi": [1] * nsrc, "neg_lo": [0] * nsrc, "neg_hi": [0] * nsrc}
+                for md in mods:
+                    k, v = md.split(":")
+                    m[k] = [int(t) for t in v.strip("[] ").split(",")]
+                _, d, n = self.reg(toks[0])
+                assert n == 2 and d % 2 == 0, ln
+
+                def half(tok, sel):
+                    if tok.startswith("%["):
+                        return np.full(64, np.float64(self.ops[tok[2:-1]][sel]))
+                    _, r, nn = self.reg(tok)
+                    assert nn == 2 and r % 2 == 0, ln
+                    return self.v[r + sel].astype(np.float64)
+                res = []
+                for hi, (sel, neg) in enumerate(((m["op_sel"], m["neg_lo"]), (m["op_sel_hi"], m["neg_hi"]))):
+                    srcs = [half(toks[1 + k], sel[k]) * (-1.0 if neg[k] else 1.0) for k in range(nsrc)]
+                    res.append((srcs[0] * srcs[1] + srcs[2]) if nsrc == 3 else (srcs[0] + srcs[1]))
+                self.v[d], self.v[d + 1] = res[0].astype(np.float32), res[1].astype(np.float32)
             elif op == "v_and_b32":
                 _, d, _ = self.reg(args[0])
                 self.v[d] = (self.src_int(args[1]) & self.src_int(args[2])).astype(np.uint32).view(np.float32)
@@ -137,8 +162,19 @@ class Wave:
             elif op == "buffer_load_dwordx4":
                 self.counts["dma"] += 1
                 assert rest.endswith("offen lds"), ln
+            elif op in ("s_add_u32", "s_sub_u32", "s_addc_u32") and re.fullmatch(r"s\d+", args[0]):
+                a, b = self.sval(args[1]), self.sval(args[2])
+                r = a + b + (1 if op == "s_addc_u32" and self.scc else 0) if op != "s_sub_u32" else a - b
+                self.scc = r >= (1 << 32) or r < 0
+                self.s[int(args[0][1:])] = r & 0xffffffff
+            elif op == "s_mov_b32" and re.fullmatch(r"s\d+", args[0]):
+                self.s[int(args[0][1:])] = self.sval(args[1])
+            elif op == "s_cselect_b32":
+                self.s[int(args[0][1:])] = self.sval(args[1]) if self.scc else self.sval(args[2])
+            elif op == "s_cmp_ge_u32":
+                self.scc = self.sval(args[0]) >= self.sval(args[1])
             elif op == "s_cmp_lt_u32":
-                self.scc = int(self.ops[args[0][2:-1]]) < int(args[1])
+                self.scc = self.sval(args[0]) < self.sval(args[1])
             elif op == "s_bitcmp1_b32":
                 self.scc = bool((int(self.ops[args[0][2:-1]]) >> int(args[1])) & 1)
             elif op == "s_cbranch_scc0":
@@ -154,7 +190,16 @@ class Wave:
             else:
                 raise AssertionError("unknown instruction: " + ln)
 
+    def sval(self, tok):
+        if re.fullmatch(r"s\d+", tok):
+            return int(self.s.get(int(tok[1:]), 0))
+        if tok.startswith("%["):
+            return int(self.ops[tok[2:-1]])
+        return int(tok, 0)
+
     def src_int(self, tok):
+        if re.fullmatch(r"s\d+", tok):
+            return np.full(64, self.sval(tok), dtype=np.int64)
         if re.fullmatch(r"\d+", tok):
             return np.full(64, int(tok), dtype=np.int64)
         if tok.startswith("%["):
@@ -175,6 +220,9 @@ def reference_chunk(lds, slot, trow, mode=0, fixmask=None):
             o = base + k * G.PLANE_S + 4 * trow * G.ROWP + 4 * n
             d = np.array([[lds[o + r * G.ROWP + j] for j in range(6)] for r in range(6)], np.float64)
             if mode:
+                for i in range(6):
+                    if (int(fixmask[16 * k + n]) >> (8 + i)) & 1:
+                        d[i, 1:4] = d[i, 0:3].copy()
                 raw = d.copy()
                 for j in range(6):
                     if (int(fixmask[16 * k + n]) >> j) & 1:
@@ -202,16 +250,21 @@ def simulate(nchunks=5, trow=2, wave=1, seed=0, mode=0):
         fixmask = rng.integers(0, 64, 64).astype(np.uint32)
     else:                                                           # reflect: column -1 (bit 0) or the one column W (bit 2..5)
         fixmask = np.where(n16 == 0, 1, np.where(n16 == 15, 1 << rng.integers(2, 6, 64), 0)).astype(np.uint32)
+    if mode:
+        fixmask[0] |= 1 | (256 << 1)                                # lane (n16 = 0, k4 = 0): row 1 fetched one column off
+        fixmask[5] |= 256 << 4
     rflags = 0 if mode == 0 else (2 | (4 if mode == 2 else 0))
 
     def operands(slot_rd):
-        return {"pa0": pa0, "wa0": wa0, "s_rd": slot_rd * G.BUF_BYTES, "s_five": 5.0, "s_wave": wave, "s_rflags": rflags,
-                "fixmask": fixmask.view(np.float32)}
+        assert wv.s.get(G.S_RD, 0) == slot_rd * G.BUF_BYTES, (wv.s, slot_rd)       # the read cursor is the statements' own
+        return {"pa0": pa0, "wa0": wa0, "s_five": 5.0, "s_wave": wave, "s_rflags": rflags, "fixmask": fixmask.view(np.float32),
+                "k4": (4.0, 4.0), "k5": (5.0, 5.0), "k2": (2.0, 2.0), "k41": (4.0, 1.0), "s_inc": 4 * 1920 * 1080 * 4, "s_winc": 4 * 36 * 4 * 64, "s_dma_end": 4 * G.BUF_BYTES + wave * 1024}
 
     def fill(slot):
         b = slot * (G.IN_FLOATS + G.W_FLOATS)
         lds[b:b + G.IN_FLOATS + G.W_FLOATS] = rng.standard_normal(G.IN_FLOATS + G.W_FLOATS).astype(np.float32)
 
+    wv.s[G.S_DMA] = wave * 1024
     fill(0)
     chunk_slots = [0]
     wv.run(prime, operands(0))
