@@ -98,11 +98,11 @@ class Emitter:
         self.raw("ds_read_b%d v[%d:%d], v%d offset:%d" % (width, dst, dst + n - 1, addr, offset))
         self.pending.append(set(regs))
 
-    def mfma(self, h, p, vb):
+    def mfma(self, h, p, vb, first=False):
         a, b = ureg(h, p), vb
         self.need([a, b])
         acc = acc_name(h, p)
-        self.raw("v_mfma_f32_16x16x4_f32 %s, v%d, v%d, %s" % (acc, a, b, acc))
+        self.raw("v_mfma_f32_16x16x4_f32 %s, v%d, v%d, %s" % (acc, a, b, "0" if first else acc))
 
 
 def transform_ops(x, out, tmp, five):
@@ -155,7 +155,9 @@ def row_pass_ops(s, i, vb, five):
     return ops
 
 
-# Packed forms (v_pk_fma_f32 / v_pk_add_f32: two fp32 lanes per instruction).  On gfx950 an fp32 MFMA and the vector ALU
+# Packed forms (v_pk_fma_f32 / v_pk_add_f32: two fp32 lanes per instruction).  An inline constant (4.0, 2.0) sits in the
+# low half of a packed source only, so op_sel_hi = 0 for that source makes both lanes read it; 5 and the pair (4, 1) are
+# SGPR pairs.  On gfx950 an fp32 MFMA and the vector ALU
 # do not overlap -- measured: a body with only its 72 MFMAs takes 2392 cycles, with the 144 scalar transform operations
 # spread between them 3471, grouped 3056 -- so every transform INSTRUCTION is paid in full and halving their number is the
 # lever.  Same fused operations, same operands as the scalar forms: bit-identical results.
@@ -179,17 +181,17 @@ def column_pass_pk(s, j):
     two = lambda r: [r, r + 1]
     ops = [
         ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(C), P(x[2]), P(x[4])), two(x[2]) + two(x[4]), two(C)),
-        ("v_pk_fma_f32 %s, %%[k4], %s, %s" % (P(x[0]), P(x[0]), P(C)), two(x[0]) + two(C), two(x[0])),
-        ("v_pk_fma_f32 %s, %%[k4], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(A), P(x[2]), P(x[4])), two(x[2]) + two(x[4]), two(A)),
-        ("v_pk_fma_f32 %s, %%[k4], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(B), P(x[1]), P(x[3])), two(x[1]) + two(x[3]), two(B)),
+        ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1]" % (P(x[0]), P(x[0]), P(C)), two(x[0]) + two(C), two(x[0])),
+        ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(A), P(x[2]), P(x[4])), two(x[2]) + two(x[4]), two(A)),
+        ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(B), P(x[1]), P(x[3])), two(x[1]) + two(x[3]), two(B)),
         ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(C), P(x[4]), P(x[2])), two(x[4]) + two(x[2]), two(C)),
         ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(D), P(x[3]), P(x[1])), two(x[3]) + two(x[1]), two(D)),
         ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(x[5]), P(x[3]), P(x[5])), two(x[3]) + two(x[5]), two(x[5])),
-        ("v_pk_fma_f32 %s, %%[k4], %s, %s" % (P(x[5]), P(x[1]), P(x[5])), two(x[1]) + two(x[5]), two(x[5])),
+        ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1]" % (P(x[5]), P(x[1]), P(x[5])), two(x[1]) + two(x[5]), two(x[5])),
         ("v_pk_add_f32 %s, %s, %s" % (P(x[1]), P(A), P(B)), two(A) + two(B), two(x[1])),
         ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(x[2]), P(A), P(B)), two(A) + two(B), two(x[2])),
-        ("v_pk_fma_f32 %s, %%[k2], %s, %s" % (P(x[3]), P(D), P(C)), two(D) + two(C), two(x[3])),
-        ("v_pk_fma_f32 %s, %%[k2], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(x[4]), P(D), P(C)), two(D) + two(C), two(x[4])),
+        ("v_pk_fma_f32 %s, 2.0, %s, %s op_sel_hi:[0,1,1]" % (P(x[3]), P(D), P(C)), two(D) + two(C), two(x[3])),
+        ("v_pk_fma_f32 %s, 2.0, %s, %s op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(x[4]), P(D), P(C)), two(D) + two(C), two(x[4])),
     ]
     return ops
 
@@ -203,13 +205,13 @@ def row_pass_pk(s, i, vb):
     two = lambda r: [r, r + 1]
     ops = [
         ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(I), P(x23), P(x45)), two(x23) + two(x45), two(I)),          # (-5 x2 + x4, -5 x3 + x5)
-        ("v_pk_fma_f32 %s, %%[k4], %s, %s" % (P(O0), P(x01), P(I)), two(x01) + two(I), two(O0)),                                           # (v0, v5)
+        ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1]" % (P(O0), P(x01), P(I)), two(x01) + two(I), two(O0)),                                           # (v0, v5)
         ("v_pk_fma_f32 %s, %%[k41], %s, %s op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(PR), P(x23), P(x45)),
          two(x23) + two(x45), two(PR)),                                                                                                    # (p, r) = (x4 - 4 x2, x4 - x2)
         ("v_pk_fma_f32 %s, %%[k41], %s, %s op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(QS), P(x01), P(x23)),
          two(x01) + two(x23), two(QS)),                                                                                                    # (q, s) = (x3 - 4 x1, x3 - x1)
         ("v_pk_add_f32 %s, %s, %s op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" % (P(O1), P(PR), P(QS)), two(PR) + two(QS), two(O1)),         # (v1, v2) = (p + q, p - q)
-        ("v_pk_fma_f32 %s, %%[k2], %s, %s op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_hi:[1,0,0]" % (P(O2), P(QS), P(PR)), two(QS) + two(PR), two(O2)),   # (v3, v4) = (2 s + r, -2 s + r)
+        ("v_pk_fma_f32 %s, 2.0, %s, %s op_sel:[0,1,1] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" % (P(O2), P(QS), P(PR)), two(QS) + two(PR), two(O2)),   # (v3, v4) = (2 s + r, -2 s + r)
     ]
     return ops
 
@@ -360,7 +362,8 @@ def mfma_order():
     return [(i, j, h) for i in range(6) for j in range(6) for h in range(2)]
 
 
-def gen_body(P, pending_in):
+def gen_body(P, pending_in, first=False):
+    """first: the item's first chunk -- the MFMAs start from 0 instead of the accumulators (nothing has to clear them)."""
     cur, nxt = P, 1 - P
     five = "%[s_five]"
     em = Emitter(pending_in)
@@ -438,7 +441,7 @@ def gen_body(P, pending_in):
     # ---- emit ----
     addr_setup(em)
     for m, (i, j, h) in enumerate(order):
-        em.mfma(h, 6 * i + j, vreg(VBUF[i % 2], j))
+        em.mfma(h, 6 * i + j, vreg(VBUF[i % 2], j), first)
         if m == 0:
             entry_wait(em, 2)
         for fn, _ in sched[m]:
@@ -488,11 +491,11 @@ def operands_macro(kind):
         outs.append('"=&{v%d}"(ST.tmp[%d])' % (r, k))
     outs.append('"+{s%d}"(ST.s_rd)' % S_RD)
     ins += ['[pa0] "v"(ST.pa0)', '[wa0] "v"(ST.wa0)', '[fixmask] "v"(ST.fixmask)', '[s_rflags] "s"(ST.s_rflags)',
-            '[s_wave] "s"(ST.s_wave)', '[s_five] "s"(ST.s_five)', '[k4] "s"(ST.k4)', '[k5] "s"(ST.k5)', '[k2] "s"(ST.k2)', '[k41] "s"(ST.k41)']
+            '[s_wave] "s"(ST.s_wave)'] + (['[k5] "s"(ST.k5)', '[k41] "s"(ST.k41)'] if PK else ['[s_five] "s"(ST.s_five)'])
     if kind != "prime":
         outs += ['"+{s[%d:%d]}"(ST.rin)' % (S_RIN, S_RIN + 3), '"+{s[%d:%d]}"(ST.rw)' % (S_RW, S_RW + 3), '"+{s%d}"(ST.s_dma)' % S_DMA]
         ins += ['[wvoff] "v"(ST.wvoff)'] + ['[voff%d] "v"(ST.voff[%d])' % (t, t) for t in range(5)]
-        ins += ['[s_inc] "s"(ST.s_inc)', '[s_winc] "s"(ST.s_winc)', '[s_dma_end] "s"(ST.s_dma_end)'] + ['[s_w%d] "s"(ST.s_w[%d])' % (t, t) for t in range(5)]
+        ins += ['[s_first] "s"(ST.s_first)', '[s_inc] "s"(ST.s_inc)', '[s_winc] "s"(ST.s_winc)', '[s_dma_end] "s"(ST.s_dma_end)'] + ['[s_w%d] "s"(ST.s_w[%d])' % (t, t) for t in range(5)]
     return outs, ins
 
 
@@ -507,6 +510,7 @@ def main(out_path):
     b0, t0 = gen_body(0, pend[0])
     b1, t1 = gen_body(1, pend[1])
     assert t1 == pend[0] and t0 == pend[1], "tail reads did not reach a fixed point"
+    b0f, b1f = gen_body(0, pend[0], True)[0], gen_body(1, pend[1], True)[0]
     n_mfma = sum(1 for ln in b0 if ln.startswith("v_mfma"))
     n_valu = sum(1 for ln in b0 if ln.startswith(("v_fma", "v_add_f32", "v_sub", "v_pk_")))
     assert ELIM or (n_mfma == 72 and n_valu == (72 if PK else 144)), (n_mfma, n_valu)
@@ -524,12 +528,17 @@ def main(out_path):
                 "// or the compiler would copy all 288 into VGPRs)\n")
         f.write("#define W4M_ACCV %d\n" % ACCV)
         f.write("#define W4M_ASM_ZERO \\\n" + c_string(zero).replace("\n", " \\\n") + "\n")
-        f.write("#define W4M_ASM_BODY0 \\\n" + c_string(b0).replace("\n", " \\\n") + "\n")
-        f.write("#define W4M_ASM_BODY1 \\\n" + c_string(b1).replace("\n", " \\\n") + "\n")
+        # One statement per parity holds BOTH forms of the chunk -- accumulating, and (an item's first chunk, %[s_first] != 0)
+        # starting from srcC = 0, so nothing ever has to clear the 288 accumulator registers -- behind one scalar branch: two
+        # statements merged by an if / else in C++ would need phi nodes of the pinned scalar outputs, which the compiler
+        # cannot place ("illegal VGPR to SGPR copy").
+        both = lambda normal, first: ["s_cmp_lg_u32 %[s_first], 0", "s_cbranch_scc1 8f"] + normal + ["s_branch 9f", "8:"] + first + ["9:"]
+        f.write("#define W4M_ASM_BODY0 \\\n" + c_string(both(b0, b0f)).replace("\n", " \\\n") + "\n")
+        f.write("#define W4M_ASM_BODY1 \\\n" + c_string(both(b1, b1f)).replace("\n", " \\\n") + "\n")
         for kind, tag in (("prime", "PRIME"), (0, "BODY0"), (1, "BODY1"), ("drain", "DRAIN"), ("zero", "ZERO")):
             outs, ins = operands_macro(kind)
             f.write("#define W4M_OPERANDS_%s(ST) \\\n    : " % tag + ", \\\n      ".join(outs) + " \\\n    : " + ", \\\n      ".join(ins) + "\n")
-    return prime, b0, b1
+    return prime, b0, b1, b0f, b1f
 
 
 if __name__ == "__main__":

@@ -77,13 +77,13 @@ class Wave:
             if op == "v_mfma_f32_16x16x4_f32":
                 self.counts["mfma"] += 1
                 f, d0, n = self.reg(args[0])
-                assert n == 4 and args[3] == args[0]
+                assert n == 4 and args[3] in (args[0], "0")
                 A, B = self.src(args[1]).astype(np.float64), self.src(args[2]).astype(np.float64)
                 bank = self.v if f == "v" else self.a
                 D = np.zeros((16, 16), np.float64)                  # [cout row][tile col]
                 for r in range(4):
                     for l in range(64):
-                        D[4 * (l >> 4) + r, l & 15] = bank[d0 + r, l]
+                        D[4 * (l >> 4) + r, l & 15] = 0.0 if args[3] == "0" else bank[d0 + r, l]
                 for k in range(4):
                     a_col = np.array([A[16 * k + i] for i in range(16)])         # A[i][k]: lane 16 k + i
                     b_row = np.array([B[16 * k + j] for j in range(16)])         # B[k][j]: lane 16 k + j
@@ -115,6 +115,8 @@ class Wave:
                 assert n == 2 and d % 2 == 0, ln
 
                 def half(tok, sel):
+                    if re.fullmatch(r"-?\d+\.\d+", tok):             # inline constant: low half only
+                        return np.full(64, np.float64(float(tok)) if sel == 0 else 0.0)
                     if tok.startswith("%["):
                         return np.full(64, np.float64(self.ops[tok[2:-1]][sel]))
                     _, r, nn = self.reg(tok)
@@ -238,9 +240,11 @@ def reference_chunk(lds, slot, trow, mode=0, fixmask=None):
 
 def simulate(nchunks=5, trow=2, wave=1, seed=0, mode=0):
     rng = np.random.default_rng(seed)
-    prime, b0, b1 = G.main("/dev/null")
+    prime, b0, b1, b0f, b1f = G.main("/dev/null")
     lds = np.zeros(G.NBUF * (G.IN_FLOATS + G.W_FLOATS) + 512, np.float32)
     wv = Wave(trow, lds)
+    wv.a[:] = 123.0                                  # (the first chunk's statements must not read the accumulators)
+    wv.v[G.ACCV:] = 321.0
     lane = np.arange(64)
     n16, k4 = lane & 15, lane >> 4
     pa0 = ((k4 * G.PLANE_S + 4 * trow * G.ROWP + 4 * n16) * 4).astype(np.uint32).view(np.float32)
@@ -273,7 +277,7 @@ def simulate(nchunks=5, trow=2, wave=1, seed=0, mode=0):
         nxt = (c + 1) % G.NBUF
         fill(nxt)                                  # chunk c+1 has landed by the time body c reads it
         chunk_slots.append(nxt)
-        wv.run(b0 if c % 2 == 0 else b1, operands(nxt))
+        wv.run((b0f if c == 0 else b0) if c % 2 == 0 else b1, operands(nxt))
     wv.retire(0)
     got = np.zeros_like(want)
     for h in range(2):
