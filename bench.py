@@ -111,10 +111,6 @@ def usable_cores():
     if quota is not None:
         how += f", cgroup cpu quota: {quota:g}"
         avail = max(1, min(avail, int(quota + 0.5)))
-    elif avail > 32:
-        # no quota visible although the mask shows a whole host: stay at the share a one-GPU box is given
-        how += ", no cgroup quota visible: capped at the 16-core share of a one-GPU box"
-        avail = 16
     return avail, how
 
 
@@ -126,6 +122,8 @@ def cpu_baseline(hw=(1080, 1920), runs=3, warmup_hw=(256, 256), threads=None):
     process can use (usable_cores).  A line per run goes to stderr so a long CPU leg never looks hung."""
     from oracle import pipeline_cpu, synth
     avail, how = usable_cores()
+    if threads:
+        how += f", --cpu-threads {threads}"
     threads = max(1, min(threads or avail, avail))
     torch.set_num_threads(threads)
     print(f"[bench] cpu_baseline: {threads} threads ({how})", file=sys.stderr, flush=True)
@@ -144,7 +142,7 @@ def cpu_baseline(hw=(1080, 1920), runs=3, warmup_hw=(256, 256), threads=None):
         print(f"[bench] cpu_baseline run {i + 1}/{runs}: {times[-1]:.1f} s", file=sys.stderr, flush=True)
     med = float(np.median(times))
     st = stages[int(np.argsort(times)[len(times) // 2])]
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "cores_note": f"all usable cores ({how})",
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "cores_note": f"threads used: {threads} ({how})",
             "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{runs} timed fused frame(s) at {w}x{h} (the benchmark workload itself) after a {warmup_hw[1]}x{warmup_hw[0]} "
                       f"warm-up frame; median {med:.1f} s of {[round(t, 1) for t in times]} on {threads} threads",
@@ -166,11 +164,42 @@ def spawn_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    sys.exit(subprocess.call(cmd, env=env))
+    # per-rank logs (the ranks' output still streams to this console, prefixed with its rank): when a rank fails, the
+    # launcher's summary names it, and the stderr of the rank that failed FIRST is repeated below it
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="vfi_bench_logs_") as logs:
+        cmd[3:3] = ["--log-dir", logs, "--tee", "3"]
+        rc = subprocess.call(cmd, env=env)
+        if rc != 0:
+            rank, tail = first_failing_rank_log(logs)
+            if rank is not None:
+                print(f"[bench] exit code {rc}; stderr of the first failing rank ({rank}):\n{tail}", file=sys.stderr, flush=True)
+    sys.exit(rc)
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
-KERNEL_SOURCES = {"conv3x3_winograd4_kernel": "vfi_conv_winograd4.hip", "conv3x3_winograd_kernel": "vfi_conv_winograd.hip"}
+def first_failing_rank_log(log_dir, lines=40):
+    """(rank, last lines of its stderr) of the rank whose stderr log shows a failure and stopped growing first, from a
+    torch.distributed.run --log-dir tree (<run id>/attempt_N/<rank>/stderr.log); (None, "") when there is none."""
+    found = []
+    for root, _dirs, files in os.walk(log_dir):
+        if "stderr.log" in files and os.path.basename(root).isdigit():
+            path = os.path.join(root, "stderr.log")
+            try:
+                with open(path, errors="replace") as f:
+                    text = f.read()
+            except OSError:
+                continue
+            if "[vfi shard]" in text or "Traceback" in text or "Error" in text:
+                found.append((os.path.getmtime(path), int(os.path.basename(root)), text))
+    if not found:
+        return None, ""
+    _, rank, text = min(found)
+    return rank, "\n".join(text.rstrip().splitlines()[-lines:])
+
+
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
+KERNEL_SOURCES = {"conv3x3_winograd4m_kernel": "vfi_conv_winograd4m.hip", "conv3x3_winograd4_kernel": "vfi_conv_winograd4.hip",
+                  "conv3x3_winograd_kernel": "vfi_conv_winograd.hip"}
 
 
 def kernel_source_hash(kernel):
@@ -217,6 +246,10 @@ def main():
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture each in-flight frame's ~700 launches into a hipGraph (torch.cuda.CUDAGraph) and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU oracle leg (default: every core the process can use -- affinity mask cut to the cgroup quota)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions of --steps steps, back to back with the same barriers; `value` is the FIRST, all of them go to value_repeats")
     ap.add_argument("--cpu-baseline-runs", type=int, default=3,
                     help="timed full-size runs of the CPU oracle (median reported); 3 = BASELINE.md's protocol, ~4 minutes")
     ap.add_argument("--steps-720p", type=int, default=20,
@@ -227,7 +260,10 @@ def main():
         spawn_ranks(args.gpus)                               # never returns
 
     from vfi_amd import _lib, shard
-    rank, local_rank, world = shard.init_distributed()
+    try:
+        rank, local_rank, world = shard.init_distributed()
+    except shard.ShardError:
+        sys.exit(3)                                          # (rank and backend error are on stderr already)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     local_dev = local_rank % torch.cuda.device_count()     # (== local_rank on a real node; lets 2 ranks rehearse on 1 GPU)
@@ -235,7 +271,10 @@ def main():
     device = torch.device("cuda", local_dev)
     h, w = args.height, args.width
 
-    runners, n_weights = build_runner(device, args.streams)
+    try:
+        runners, n_weights = build_runner(device, args.streams)        # (RCCL's first collective: the weight broadcast)
+    except shard.ShardError:
+        sys.exit(4)
     streams = [torch.cuda.Stream(device=device) for _ in runners]
     pairs = synthetic_pairs(4, h, w, device, seed=rank)
     torch.cuda.synchronize()
@@ -287,12 +326,20 @@ def main():
         for i in range(2):
             step(i)
         barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    frames, elapsed = shard.reduce_counters(args.steps, elapsed, device)
+    def timed_region():
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        barrier()
+        return shard.reduce_counters(args.steps, time.perf_counter() - t0, device)
+
+    try:
+        frames, elapsed = timed_region()
+        # the same region again (same barriers, max over ranks each): how far `value` moves from run to run on this box --
+        # a gain smaller than value_spread is not a measurement
+        repeats = [frames / elapsed] + [(lambda fe: fe[0] / fe[1])(timed_region()) for _ in range(max(0, args.repeats - 1))]
+    except shard.ShardError:
+        sys.exit(5)
 
     # second size north_star names: the same fused frame at 1280x720, same barriers, same in-flight scheme (eager)
     value_720p = None
@@ -325,6 +372,10 @@ def main():
                            "frame": [h, w], "weights": f"random-init, {n_weights} params broadcast from rank 0",
                            "sharding": f"frame pairs over {world} rank(s), no data-path collective",
                            "frames_in_flight_per_gpu": args.streams, "hip_graph": bool(args.graph)}}
+        line["value_repeats"] = repeats
+        line["value_spread"] = (max(repeats) - min(repeats)) / float(np.median(repeats))
+        line["value_repeats_note"] = (f"{len(repeats)} timed regions of {args.steps} steps back to back, same barriers; `value` is the first; "
+                                      "value_spread = (max - min) / median")
         if value_720p is not None:
             line["value_720p"] = value_720p
             line["value_720p_note"] = f"same fused frame at 1280x720, {args.steps_720p} timed steps after the headline run, frames/s of all ranks"
@@ -366,6 +417,7 @@ def main():
                                 "algorithmic_gflop_per_launch": d["work"] / d["calls"] / 1e9}
             if traffic_note:
                 line["roofline"]["traffic_note"] = traffic_note
+            line["roofline"]["rocprof_kernel_name"] = dom
             if "winograd4" in dom:
                 # `achieved` counts the Winograd algorithm's own multiply-adds (36 per 4x4 outputs and channel pair: what
                 # the matrix cores execute); the same convolutions done directly are 144
@@ -393,7 +445,7 @@ def main():
                                                "calls": v["calls"], "ms_per_frame": v["seconds"] * 1e3})
             line["stage_ms_isolated"] = {k: round(v["seconds"] * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["seconds"])[:14]}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline((h, w), runs=args.cpu_baseline_runs)
+            line["cpu_baseline"] = cpu_baseline((h, w), runs=args.cpu_baseline_runs, threads=args.cpu_threads or None)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

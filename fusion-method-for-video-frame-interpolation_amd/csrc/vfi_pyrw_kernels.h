@@ -13,6 +13,7 @@
 // (vfi_wfft.h); a workgroup only shares the small tables (stage twiddles; Bluestein's chirp and filter) in LDS.
 // Roofline: HBM -- per coefficient 8 B of T written and read once plus the 8 B of (phase, amplitude).
 #pragma once
+#include <mutex>
 #include "vfi_pyramid_wave.h"
 #include "vfi_wfft.h"
 #include "vfi_wfft_configs.h"
@@ -254,10 +255,15 @@ __global__ __launch_bounds__(C::TEAM > 64 ? C::TEAM : kMaxThreads, 2) void rows_
                     if (BLU && r >= I::R0_BLU) { v[q * I::R0 + r] = make_float2(0.0f, 0.0f); continue; }
                     const int pos = i + r * I::T0;
                     const unsigned ve = BLU && pos >= n ? kOob : vo;          // (positions past the row read 0: amplitude 0)
-                    // sin / cos on the hardware units (v_sin_f32 / v_cos_f32: absolute error <= 4e-7 for the phases of a pyramid,
-                    // |p| <= a few pi; libm's sincosf carries a Payne-Hanek path and ~40 registers into the load phase)
+                    // sin / cos on the hardware units (v_sin_f32 / v_cos_f32 take REVOLUTIONS and are only valid up to 256 of
+                    // them, with an absolute error that grows with the argument: <= 4e-7 for |p| <= pi).  The phase is a
+                    // caller's value (vfi_pyr_synthesize), so it is reduced first: r - rint(r) is exact in fp32 and leaves
+                    // |p| <= pi untouched (same bits as without it); libm's sincosf would carry a Payne-Hanek path and ~40
+                    // registers into the load phase.
                     const float ph = ld1(rP, ve, r * I::T0 * 4);
-                    const float sn = __sinf(ph), cs = __cosf(ph);
+                    float rev = ph * 0.15915494309189535f;
+                    rev -= rintf(rev);
+                    const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
                     const float am = ld1(rA, ve, r * I::T0 * 4);
                     const float2 x = fft::load_value<false>(make_float2(cs * am, sn * am), BLU ? m.ch[pos] : make_float2(0.0f, 0.0f), BLU);
                     v[q * I::R0 + r] = (!BLU || pos < n) ? x : make_float2(0.0f, 0.0f);
@@ -466,7 +472,10 @@ struct Occupancy { int blocks = 0, cus = 0; };
 template <auto kernel>
 inline Occupancy occupancy_of(int threads, size_t lds) {
     Occupancy o;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        o.blocks = -1;          // (the launch helper reports it)
+        return o;
+    }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o.blocks, kernel, threads, lds) != hipSuccess || o.blocks < 1) o.blocks = 1;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -476,39 +485,56 @@ inline Occupancy occupancy_of(int threads, size_t lds) {
 }
 
 struct Pick { int threads = 0, blocks = 0, cus = 0; };
+// (one lock for the per-kernel, per-device geometry caches below: plans on different host threads launch the same kernels)
+inline std::mutex &pick_mutex() {
+    static std::mutex mu;
+    return mu;
+}
 
 // row passes: waves per workgroup = the choice (4 or 8) that keeps more waves resident per CU (tables are per workgroup)
 template <class C, bool BLU, auto kernel, typename A>
 inline int launch_rows(const A &a, int nbatch, hipStream_t s) {
     static Pick cache[kMaxDevices];
-    Pick &p = cache[current_device()];
-    if (!p.threads) {
-        if (C::TEAM > 64) {      // a team of waves is a workgroup of its own
-            const Occupancy o = occupancy_of<kernel>(C::TEAM, Lds<C, BLU>::bytes(1));
-            p.threads = C::TEAM; p.blocks = o.blocks; p.cus = o.cus;
-        } else {
-            const Occupancy o4 = occupancy_of<kernel>(256, Lds<C, BLU>::bytes(4)), o8 = occupancy_of<kernel>(512, Lds<C, BLU>::bytes(8));
-            if (o8.blocks * 8 > o4.blocks * 4) { p.threads = 512; p.blocks = o8.blocks; } else { p.threads = 256; p.blocks = o4.blocks; }
-            p.cus = o4.cus;
+    Pick p;
+    {
+        std::lock_guard<std::mutex> lock(pick_mutex());
+        Pick &c = cache[current_device()];
+        if (!c.threads) {
+            if (C::TEAM > 64) {      // a team of waves is a workgroup of its own
+                const Occupancy o = occupancy_of<kernel>(C::TEAM, Lds<C, BLU>::bytes(1));
+                if (o.blocks < 0) return vfi::fail(VFI_ERR_LAUNCH, "pyramid wave row pass (M = %d): the kernel's LDS attribute was rejected", C::M);
+                c.blocks = o.blocks; c.cus = o.cus; c.threads = C::TEAM;
+            } else {
+                const Occupancy o4 = occupancy_of<kernel>(256, Lds<C, BLU>::bytes(4)), o8 = occupancy_of<kernel>(512, Lds<C, BLU>::bytes(8));
+                if (o4.blocks < 0 || o8.blocks < 0) return vfi::fail(VFI_ERR_LAUNCH, "pyramid wave row pass (M = %d): the kernel's LDS attribute was rejected", C::M);
+                if (o8.blocks * 8 > o4.blocks * 4) { c.blocks = o8.blocks; c.cus = o4.cus; c.threads = 512; } else { c.blocks = o4.blocks; c.cus = o4.cus; c.threads = 256; }
+            }
         }
+        p = c;
     }
     const int nw = p.threads / C::TEAM;
     int grid = (nbatch + nw - 1) / nw;
     if (grid > p.blocks * p.cus) grid = p.blocks * p.cus;
     const size_t lds = Lds<C, BLU>::bytes(nw);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(p.threads), lds, s, a);
-    return VFI_OK;
+    return vfi::check_launch("pyramid wave row pass");
 }
 
 // column passes: 16 adjacent columns (one 128-byte line) per workgroup where the lines per wave allow it
 template <class C, bool BLU, auto kernel, typename A>
 inline int launch_cols(const A &a, int w, int items_per_tile, hipStream_t s) {
     static Pick cache[kMaxDevices];
-    Pick &p = cache[current_device()];
-    if (!p.threads) {
-        p.threads = C::TEAM > 64 ? C::TEAM : (C::L * 4 >= 16 ? 256 : 512);
-        const Occupancy o = occupancy_of<kernel>(p.threads, Lds<C, BLU>::bytes(p.threads / C::TEAM));
-        p.blocks = o.blocks; p.cus = o.cus;
+    Pick p;
+    {
+        std::lock_guard<std::mutex> lock(pick_mutex());
+        Pick &c = cache[current_device()];
+        if (!c.threads) {
+            const int threads = C::TEAM > 64 ? C::TEAM : (C::L * 4 >= 16 ? 256 : 512);
+            const Occupancy o = occupancy_of<kernel>(threads, Lds<C, BLU>::bytes(threads / C::TEAM));
+            if (o.blocks < 0) return vfi::fail(VFI_ERR_LAUNCH, "pyramid wave column pass (M = %d): the kernel's LDS attribute was rejected", C::M);
+            c.blocks = o.blocks; c.cus = o.cus; c.threads = threads;
+        }
+        p = c;
     }
     const int nw = p.threads / C::TEAM, tilew = nw * C::L, ntile = (w + tilew - 1) / tilew;
     const int nitem = items_per_tile * ntile, per = (nitem + 7) / 8;
@@ -517,25 +543,31 @@ inline int launch_cols(const A &a, int w, int items_per_tile, hipStream_t s) {
     if (grid > cap) grid = cap;
     const size_t lds = Lds<C, BLU>::bytes(nw);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(p.threads), lds, s, a);
-    return VFI_OK;
+    return vfi::check_launch("pyramid wave column pass");
 }
 
 // synthesis columns: a workgroup is the four bands of L columns
 template <class C, bool BLU, auto kernel>
 inline int launch_syn(const SynColsArgs &a, hipStream_t s) {
     static Pick cache[kMaxDevices];
-    Pick &p = cache[current_device()];
+    Pick p;
     const size_t lds = Lds<C, BLU>::bytes(kBands);
-    if (!p.blocks) {
-        const Occupancy o = occupancy_of<kernel>(256, lds);
-        p.blocks = o.blocks; p.cus = o.cus;
+    {
+        std::lock_guard<std::mutex> lock(pick_mutex());
+        Pick &c = cache[current_device()];
+        if (!c.blocks) {
+            const Occupancy o = occupancy_of<kernel>(256, lds);
+            if (o.blocks < 0) return vfi::fail(VFI_ERR_LAUNCH, "pyramid wave synthesis columns (M = %d): the kernel's LDS attribute was rejected", C::M);
+            c.blocks = o.blocks; c.cus = o.cus;
+        }
+        p = c;
     }
     const int ntile = (a.w + C::L - 1) / C::L, nitem = a.N * ntile, per = (nitem + 7) / 8;
     int grid = 8 * per;
     const int cap = (p.blocks * p.cus) / 8 * 8;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, a);
-    return VFI_OK;
+    return vfi::check_launch("pyramid wave synthesis columns");
 }
 
 constexpr bool blu_capable(int m) {

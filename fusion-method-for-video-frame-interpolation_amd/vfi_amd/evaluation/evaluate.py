@@ -134,11 +134,22 @@ def build_models(args):
     return adacof_model, fusion_net
 
 
-def _wait_for(path, timeout_s=24 * 3600.0, poll_s=2.0):
-    """File-based hand-off between ranks (no collective on the data path): blocks until `path` exists."""
+def _run_token():
+    """What the ranks of ONE launch share and no other launch has: torchrun's run id and rendezvous port.  The hand-off
+    marker carries it, so a marker left behind in a reused --base_dir is never taken for this run's."""
+    return "{}_{}".format(os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.environ.get("MASTER_PORT", "0"))
+
+
+def _wait_for(path, failed_path, timeout_s=None, poll_s=2.0):
+    """File-based hand-off between ranks (no collective on the data path): blocks until `path` exists; gives up when the
+    producing rank has left `failed_path` behind or after VFI_EVAL_HANDOFF_TIMEOUT_S (default 2 h)."""
     import time
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("VFI_EVAL_HANDOFF_TIMEOUT_S", 2 * 3600.0))
     t0 = time.monotonic()
     while not os.path.exists(path):
+        if os.path.exists(failed_path):
+            raise RuntimeError("evaluate: rank 0 failed while interpolating ({})".format(failed_path))
         if time.monotonic() - t0 > timeout_s:
             raise TimeoutError("evaluate: waited {:.0f} s for {}".format(timeout_s, path))
         time.sleep(poll_s)
@@ -163,12 +174,17 @@ def eval(args, rank=None, world=None):           # noqa: A001  (the reference's 
     adacof_model, fusion_net = build_models(args)
     if getattr(args, "vimeo_testset", False):
         # the triplet list is one flat file: rank 0 interpolates it, the others wait for its marker before they score
-        marker = os.path.join(img_output_dir, ".vimeo_interpolated")
+        marker = os.path.join(img_output_dir, ".vimeo_interpolated." + _run_token())
+        failed = marker + ".failed"
         if rank == 0:
-            interpolate.interpolate_dataset(args, adacof_model, fusion_net)
+            try:
+                interpolate.interpolate_dataset(args, adacof_model, fusion_net)
+            except BaseException:
+                open(failed, "w").close()               # the waiting ranks stop instead of polling until their timeout
+                raise
             open(marker, "w").close()
         else:
-            _wait_for(marker)
+            _wait_for(marker, failed)
         args.test_sets = [os.path.basename(x) for x in sorted(glob.glob(os.path.join(root, "vimeo_interp_test", "target", "*")))]
     mine = [t for i, t in enumerate(args.test_sets) if i % world == rank]
     if not getattr(args, "vimeo_testset", False):

@@ -79,8 +79,9 @@ def _winograd_work(n, cin, cout, h, w, residual=False, pooled=False, act="relu")
     decision (vfi_conv2d_algo): F(4x4,3x3) -- 36 multiply-adds per 4x4 outputs and channel pair -- or F(2x2,3x3) -- 16 per
     2x2 outputs."""
     algo = _lib.lib().vfi_conv2d_algo(n, cin, h, w, cout, 3, int(bool(residual)), int(bool(pooled)), ACT[act])
-    if algo == 2:
-        return ("flop", 2.0 * n * cin * cout * 36 * (h * w / 16.0), "conv3x3_winograd4_kernel")
+    if algo == 2:       # (the M = 32 kernel unless VFI_CONV_WINOGRAD4M=0: the library reads that switch at every call)
+        name = "conv3x3_winograd4_kernel" if os.environ.get("VFI_CONV_WINOGRAD4M", "1") == "0" else "conv3x3_winograd4m_kernel"
+        return ("flop", 2.0 * n * cin * cout * 36 * (h * w / 16.0), name)
     if algo == 1:
         return ("flop", 2.0 * n * cin * cout * 16 * (h * w / 4.0), "conv3x3_winograd_kernel")
     return ("flop", 2.0 * n * cin * cout * 9 * h * w, "conv2d_mfma_kernel<3,8,%d>" % (2 if ((cout + 31) // 32 * 32) % 64 == 0 else 1))

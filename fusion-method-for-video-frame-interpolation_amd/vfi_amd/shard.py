@@ -6,18 +6,45 @@ independent frame pairs), so the clip is partitioned into contiguous blocks of p
 path needs NO collective.  Collectives used: one broadcast of all model parameters (one flat buffer) from
 rank 0 at start-up, and one all_reduce of the (frames, seconds) counters at the end.
 """
+import datetime
 import os
+import sys
 
 import torch
 import torch.distributed as dist
+
+
+class ShardError(RuntimeError):
+    """A collective step of the sharded run failed on this rank (rendezvous, weight broadcast, counter reduction).  The
+    message names the rank, the step and the backend's own error, so that the launcher's log of the FIRST failing rank
+    says what happened; callers exit non-zero on it (bench.py, evaluation) -- never retry, never re-exec."""
 
 
 def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_distributed(backend=None):
-    """Initialises the default process group from the torchrun environment (no-op for one process)."""
+def default_timeout_s():
+    """Seconds a rank waits in the rendezvous / a collective before giving up (VFI_DIST_TIMEOUT_S, default 180): a rank
+    that died must not leave the others hanging for the backend's half-hour default."""
+    return float(os.environ.get("VFI_DIST_TIMEOUT_S", "180"))
+
+
+def _guard(what, fn):
+    rank = env_world()[0]
+    try:
+        return fn()
+    except ShardError:
+        raise
+    except Exception as e:          # noqa: BLE001 -- whatever the backend raises (DistBackendError, RuntimeError, socket errors)
+        msg = f"[vfi shard] rank {rank}: {what} failed: {type(e).__name__}: {e}"
+        print(msg, file=sys.stderr, flush=True)
+        raise ShardError(msg) from e
+
+
+def init_distributed(backend=None, timeout_s=None):
+    """Initialises the default process group from the torchrun environment (no-op for one process), with an explicit
+    timeout; a rank that cannot join raises ShardError (rank and backend error in the message and on stderr)."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -26,7 +53,9 @@ def init_distributed(backend=None):
             backend = os.environ.get("VFI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))     # (== local_rank on a real node)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        timeout = datetime.timedelta(seconds=timeout_s if timeout_s is not None else default_timeout_s())
+        _guard(f"init_process_group(backend={backend!r}, world_size={world}, timeout={timeout.total_seconds():g} s)",
+               lambda: dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout))
     return rank, local_rank, world
 
 
@@ -48,12 +77,17 @@ def broadcast_module_states(modules, src=0):
         return 0
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
     if dist.is_initialized() and dist.get_world_size() > 1:
+        what = f"broadcast of {flat.numel()} parameters from rank {src} (backend {dist.get_backend()})"
         if dist.get_backend() == "gloo" and flat.is_cuda:     # CPU rehearsal backend: stage through host memory
             host = flat.cpu()
-            dist.broadcast(host, src=src)
+            _guard(what, lambda: dist.broadcast(host, src=src))
             flat = host.to(flat.device)
         else:
-            dist.broadcast(flat, src=src)
+            def bcast():
+                dist.broadcast(flat, src=src)
+                if flat.is_cuda:
+                    torch.cuda.synchronize(flat.device)          # (an RCCL failure surfaces here, not at the enqueue)
+            _guard(what, bcast)
     off = 0
     for t in tensors:
         n = t.numel()
@@ -76,9 +110,11 @@ def reduce_counters(frames, seconds, device):
         device = torch.device("cpu")
     t = torch.tensor([float(frames)], dtype=torch.float64, device=device)
     s = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    dist.all_reduce(s, op=dist.ReduceOp.MAX)
-    return int(round(t.item())), s.item()
+    def reduce():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(s, op=dist.ReduceOp.MAX)
+        return int(round(t.item())), s.item()
+    return _guard("all_reduce of the (frames, seconds) counters", reduce)
 
 
 def interpolate_clip(runner, frames, rank, world, output_baseline=False, sink=None):

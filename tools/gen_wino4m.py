@@ -27,14 +27,15 @@ BUF_BYTES = (IN_FLOATS + W_FLOATS) * 4
 NBUF = 4
 
 # ---- register map (VGPR numbers) -------------------------------------------------------------------------------------
-TMP = [58, 60, 62, 64]          # transform temporaries: four even-aligned register PAIRS (v58..v65)
+TMP = [58, 60, 62, 64]          # column-pass temporaries: four even-aligned register PAIRS (v58..v65)
+RPK = [52, 54, 56]              # packed row pass: three pairs of its own (v52..v57), so that it can interleave with a column pass
 RTMP = [64, 65]                 # (unpacked variant: row-pass temporaries)
 PADDR, WADDR = 66, 67           # LDS byte addresses of this chunk's reads (patch / weights)
 TSET = [68, 104]                # patch sets A, B: row r at base + 6 r (6 registers)
 UBASE = 140                     # u[h][g] (4 positions of group g, 16-channel half h) at UBASE + 4 (9 h + g)
 VBUF = [212, 218]               # V rows: buffer 0 / 1 (6 registers each)
 ACCV = 224                      # accumulators 64..71 (VGPRs); 0..63 are a[0:255]
-FIRST_FREE = 58                 # the compiler keeps to v0 .. v57 inside the chunk loop
+FIRST_FREE = 52                 # the compiler keeps to v0 .. v51 inside the chunk loop
 # ---- pinned SGPRs: the request cursor lives in the body (its per-chunk arithmetic runs in the MFMAs' shadow) ----------
 S_RIN, S_RW, S_DMA, S_RD = 76, 80, 84, 85      # s[76:79] input descriptor, s[80:83] weight descriptor, LDS slot of the requests / reads
 
@@ -199,7 +200,7 @@ def column_pass_pk(s, j):
 def row_pass_pk(s, i, vb):
     """Row i of patch set s -> V row in buffer vb as the pairs (v0,v5), (v1,v2), (v3,v4): 6 packed operations."""
     x01, x23, x45 = treg(s, i, 0), treg(s, i, 2), treg(s, i, 4)
-    I, PR, QS, _ = TMP
+    I, PR, QS = RPK
     O0, O1, O2 = vb, vb + 2, vb + 4
     P = pair
     two = lambda r: [r, r + 1]
@@ -407,15 +408,33 @@ def gen_body(P, pending_in, first=False):
     # row passes of chunk c: row i+1 during the first six gaps of row i
     valu = lambda text, rd, wr: (lambda: em.valu(text, rd, wr))
     if PK:
-        # whole passes as blocks (they share the temporaries): row i+1 in the middle of row i's MFMAs, a pair of columns of the
-        # next chunk's column pass every 12 MFMAs behind the border fix-up, the next chunk's row 0 near the end
-        for i in range(5):
-            for text, rd, wr in row_pass_pk(cur, i + 1, VBUF[(i + 1) % 2]):
-                at(12 * i + 6, valu(text, rd, wr), 1)
+        # The transform operations go in a few blocks (an fp32 MFMA and a VALU operation never overlap; every switch between
+        # the two costs).  Inside a block two INDEPENDENT passes alternate instruction by instruction -- a row pass of this
+        # chunk and a piece of the next chunk's column pass -- so that a packed operation's result is not needed by the very
+        # next instruction.  W4M_MIX=0: passes as separate blocks (A/B).
+        mix = os.environ.get("W4M_MIX", "1") != "0"
+        rows = [row_pass_pk(cur, i + 1, VBUF[(i + 1) % 2]) for i in range(5)]
+        cols = [op for jj in range(3) for op in column_pass_pk(nxt, 2 * jj)]
         at(13, (lambda: border_fixup(em, nxt)), 2)
-        for jj in range(3):
-            for text, rd, wr in column_pass_pk(nxt, 2 * jj):
-                at(16 + 12 * jj, valu(text, rd, wr), 1)
+        for text, rd, wr in rows[0]:
+            at(6, valu(text, rd, wr), 1)
+        if mix:
+            for b in range(4):                                  # blocks behind MFMA 18, 30, 42, 54: row b+2 with 9 column operations
+                r, c = list(rows[b + 1]), cols[9 * b:9 * b + 9]
+                while r or c:
+                    if c:
+                        at(18 + 12 * b, valu(*c.pop(0)), 1)
+                    if r:
+                        at(18 + 12 * b, valu(*r.pop(0)), 1)
+                    if c and len(c) > len(r):
+                        at(18 + 12 * b, valu(*c.pop(0)), 1)
+        else:
+            for i in range(1, 5):
+                for text, rd, wr in rows[i]:
+                    at(12 * i + 6, valu(text, rd, wr), 1)
+            for jj in range(3):
+                for text, rd, wr in cols[12 * jj:12 * jj + 12]:
+                    at(16 + 12 * jj, valu(text, rd, wr), 1)
         for text, rd, wr in row_pass_pk(nxt, 0, VBUF[0]):
             at(64, valu(text, rd, wr), 1)
     else:
