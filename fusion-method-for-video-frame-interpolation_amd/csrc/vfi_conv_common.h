@@ -67,7 +67,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         // ELU: exp(v) - 1 from the hardware exponential (absolute error <= 1.2e-7, i.e. half an ulp of the -1 it approaches;
         // libm's expm1f keeps RELATIVE accuracy near 0, which an activation does not need, at ~28 instructions and a
         // branch per output against 5)
-        case 2: return v > 0.0f ? v : __expf(v) - 1.0f;
+        // As one median: exp(v) - 1 >= v everywhere, so {v, exp(v) - 1, 0} is ordered v < e < 0 for v < 0 (median e) and
+        // 0 < v < e for v > 0 (median v) -- v_med3_f32 instead of a compare and a select, same bits
+        case 2: return __builtin_amdgcn_fmed3f(v, __expf(v) - 1.0f, 0.0f);
         case 3: return tanhf(v);
         case 4: return 1.0f / (1.0f + expf(-v));
         default: return v;

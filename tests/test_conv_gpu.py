@@ -138,6 +138,42 @@ def test_f4x4_m32_kernel_equals_m16_kernel_bit_for_bit(n, cin, cout, h, w, pad, 
     assert err.max().item() <= 1e-4 and err.pow(2).mean().sqrt().item() <= 5e-6, (err.max().item(), err.pow(2).mean().sqrt().item())
 
 
+def test_large_conv_with_trained_weight_statistics(device):
+    """A PhaseNet-class 64 -> 64 3x3 reflect / ELU layer on the F(4x4) kernel with the statistics of the TRAINED phase_net.pt
+    instead of default init (tests/golden/trained_weight_stats.json, layer 7): weight std 0.03-0.04 with outliers up to
+    0.5, BatchNorm folded with running variances of ~0.05 (a x4-x6 gain per channel), inputs distributed like ELU outputs.
+    F(4x4)'s error depends on the operand range (its transforms multiply by up to 8): relative to the OUTPUT rms it must
+    stay at the 5e-6 rms / 1e-4 max of the unit-variance cases."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_weight_stats.json")) as f:
+        st = json.load(f)["phasenet"]
+    n, c, h, w = 3, 64, 270, 1920
+    g = torch.Generator().manual_seed(11)
+
+    def draw(key):
+        d = st[key]
+        return (torch.randn(d["shape"], generator=g, dtype=torch.float64) * d["std"] + d["mean"]).clamp_(d["min"], d["max"]).float()
+    wgt, b = draw("layers.7.feature_map.3.weight"), draw("layers.7.feature_map.3.bias")
+    bn = (draw("layers.7.feature_map.1.weight"), draw("layers.7.feature_map.1.bias"), draw("layers.7.feature_map.1.running_mean"),
+          draw("layers.7.feature_map.1.running_var"), 1e-5)
+    assert list(wgt.shape) == [64, 64, 3, 3]
+    x = F.elu(torch.randn((n, c, h, w), generator=g) * 2.0)                         # (what the previous block hands over)
+    ref = _ref(x.double(), wgt.double(), b.double(), 3, "reflect", "elu", bn=tuple(t.double() if torch.is_tensor(t) else t for t in bn))
+    pc = ops.PackedConv(wgt, b, bn=bn, device=device)
+    assert _lib_algo(n, c, c, h, w, "elu") == 2, "shape must take the F(4x4) path"
+    out = ops.conv2d(x.to(device), pc, "reflect", "elu")
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs()
+    rms = ref.pow(2).mean().sqrt().item()
+    print("trained-statistics conv: output rms %.3f, error rms %.3g max %.3g" % (rms, err.pow(2).mean().sqrt().item(), err.max().item()))
+    assert err.max().item() <= 1e-4 * max(1.0, rms) and err.pow(2).mean().sqrt().item() <= 5e-6 * max(1.0, rms), (rms, err.max().item())
+
+
+def _lib_algo(n, cin, cout, h, w, act, residual=False, pooled=False):
+    from vfi_amd import _lib
+    return _lib.lib().vfi_conv2d_algo(n, cin, h, w, cout, 3, int(residual), int(pooled), ops.ACT[act])
+
+
 def test_large_conv_with_residual_matches_torch_cpu(device):
     # the residual variant of the F(4x4) Winograd kernel (PhaseNet blocks at full resolution): act(conv + b) + residual
     n, cin, cout, h, w = 2, 16, 64, 270, 1920

@@ -38,6 +38,24 @@ def test_fusionnet_matches_reference_fixture(tag, device):
         assert np.abs(out.cpu().numpy() - g[f"out_variant{variant}"]).max() <= TOL
 
 
+def test_fusionnet_with_trained_weight_statistics_matches_oracle(device):
+    """FusionNet (5x5 direct-MFMA layers) with every tensor drawn to the mean / std / range of the reference's trained
+    fusion_net.pt (tests/golden/trained_weight_stats.json) against the oracle, both variants, at the fixture's inputs."""
+    import trained_stats
+    g = _load("fusionnet_64x64")
+    sd = trained_stats.state_dict_like_trained("fusionnet", nets_cpu.fusionnet_random_state_dict(0), seed=5)
+    net = FusionNet().to(device)
+    net.load_state_dict(sd)
+    net.eval()
+    c = lambda k: torch.from_numpy(g[k])
+    for variant in (0, 1):
+        with torch.no_grad():
+            ref = nets_cpu.fusionnet_forward(sd, c("base"), c("adacof"), c("phase"), c("other"), c("maps"), variant)
+        out = net(*(c(k).to(device) for k in ("base", "adacof", "phase", "other", "maps")), variant=variant)
+        scale = max(1.0, float(ref.abs().max()))
+        assert (out.cpu() - ref).abs().max().item() <= TOL * scale, (variant, scale)
+
+
 @pytest.mark.parametrize("tag", ["64x96", "40x50"])
 def test_adacofnet_matches_reference_fixture(tag, device):
     g = _load("adacofnet_" + tag)

@@ -276,9 +276,13 @@ def pair_720():
     return tuple(torch.from_numpy(x) for x in synth.translating_pair(11, H720, W720))
 
 
-def test_phasenet_branch_720p_matches_oracle(pair_720, device):
+@pytest.mark.parametrize("weights_kind", ["seeded", "trained-statistics"])
+def test_phasenet_branch_720p_matches_oracle(pair_720, device, weights_kind):
     """configs[1]: steerable-pyramid decompose -> PhaseNet -> reconstruct at 1280x720 (6 Lab channel-images in, 3 out;
-    reference src/fusion_net/interpolate_twoframe.py:168-188) -- HIP pyramid kernels + PhaseNet vs the oracle."""
+    reference src/fusion_net/interpolate_twoframe.py:168-188) -- HIP pyramid kernels + PhaseNet vs the oracle.
+    "trained-statistics": every tensor of the state dict drawn with the mean / std / range of the reference's trained
+    phase_net.pt (tests/golden/trained_weight_stats.json): BatchNorm running variances of 0.02-0.1 put a x3-x7 gain in front
+    of every ELU, so the F(4x4) Winograd layers run on activations of the magnitude a trained network produces."""
     import numpy as np
     from oracle import color_cpu, layout_cpu, nets_cpu, pyramid_cpu
     from vfi_amd import ops
@@ -287,6 +291,9 @@ def test_phasenet_branch_720p_matches_oracle(pair_720, device):
     from vfi_amd.values import DecompValues
     f0, _, f2 = pair_720
     sd = pipeline_cpu.seeded_weights(0)["phasenet"]
+    if weights_kind == "trained-statistics":
+        import trained_stats
+        sd = trained_stats.state_dict_like_trained("phasenet", sd, seed=3)
     height = layout_cpu.calc_pyr_height(H720, W720)
     assert height == 15
     lab = torch.cat((color_cpu.rgb2lab_single(f0), color_cpu.rgb2lab_single(f2)), 0).float()
@@ -304,7 +311,9 @@ def test_phasenet_branch_720p_matches_oracle(pair_720, device):
     pred = net(net.normalize_vals(vals, concat=bufs))
     got = pyr.inv_filter(DecompValues(0, pred.phase, pred.amplitude, pred.low_level)).cpu()
     psnr = _psnr(got, ref)
-    print("configs[1] PhaseNet branch 720p vs oracle:", psnr, "dB")
+    print("configs[1] PhaseNet branch 720p vs oracle (%s weights):" % weights_kind, psnr, "dB; output rms", float(ref.pow(2).mean().sqrt()))
+    _PARITY_LOG["720p PhaseNet branch, %s weights" % weights_kind] = psnr
+    _write_parity_log()
     assert psnr >= 60.0, psnr
 
 

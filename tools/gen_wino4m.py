@@ -318,9 +318,11 @@ def dma_piece(em, kind, t):
             em.raw("s_cbranch_scc0 1f")
         em.raw("s_add_i32 m0, s%d, %d" % (S_DMA, IN_FLOATS * 4 + 4096 * t))
         em.raw("s_nop 0")
-        em.raw("buffer_load_dwordx4 %%[wvoff], s[%d:%d], %%[s_w%d] offen lds" % (S_RW, S_RW + 3, t))
+        em.raw("buffer_load_dwordx4 %%[wvoff], s[%d:%d], %s offen lds" % (S_RW, S_RW + 3, "%[s_w0]" if t == 0 else "%[s_wt]"))
         if t == 4:
             em.raw("1:")
+        else:                                                  # the next piece's offset, long before its request reads it
+            em.raw("s_add_u32 %%[s_wt], %s, %%[s_wstep]" % ("%[s_w0]" if t == 0 else "%[s_wt]"))
 
 
 def entry_wait(em, chunks_in_flight):
@@ -510,11 +512,13 @@ def operands_macro(kind):
         outs.append('"=&{v%d}"(ST.tmp[%d])' % (r, k))
     outs.append('"+{s%d}"(ST.s_rd)' % S_RD)
     ins += ['[pa0] "v"(ST.pa0)', '[wa0] "v"(ST.wa0)', '[fixmask] "v"(ST.fixmask)', '[s_rflags] "s"(ST.s_rflags)',
-            '[s_wave] "s"(ST.s_wave)'] + (['[k5] "s"(ST.k5)', '[k41] "s"(ST.k41)'] if PK else ['[s_five] "s"(ST.s_five)'])
+            '[s_wave] "s"(ST.s_wave)'] + (['[k5] "v"(ST.k5)', '[k41] "v"(ST.k41)'] if PK else ['[s_five] "s"(ST.s_five)'])
     if kind != "prime":
         outs += ['"+{s[%d:%d]}"(ST.rin)' % (S_RIN, S_RIN + 3), '"+{s[%d:%d]}"(ST.rw)' % (S_RW, S_RW + 3), '"+{s%d}"(ST.s_dma)' % S_DMA]
         ins += ['[wvoff] "v"(ST.wvoff)'] + ['[voff%d] "v"(ST.voff[%d])' % (t, t) for t in range(5)]
-        ins += ['[s_first] "s"(ST.s_first)', '[s_inc] "s"(ST.s_inc)', '[s_winc] "s"(ST.s_winc)', '[s_dma_end] "s"(ST.s_dma_end)'] + ['[s_w%d] "s"(ST.s_w[%d])' % (t, t) for t in range(5)]
+        outs.append('[s_wt] "=&s"(ST.s_wt)')
+        ins += ['[s_first] "s"(ST.s_first)', '[s_inc] "s"(ST.s_inc)', '[s_winc] "s"(ST.s_winc)', '[s_dma_end] "s"(ST.s_dma_end)',
+                '[s_w0] "s"(ST.s_w[0])', '[s_wstep] "s"(ST.s_wstep)']
     return outs, ins
 
 

@@ -164,6 +164,8 @@ class Wave:
             elif op == "buffer_load_dwordx4":
                 self.counts["dma"] += 1
                 assert rest.endswith("offen lds"), ln
+            elif op == "s_add_u32" and args[0].startswith("%["):
+                pass                                             # (weight piece offsets: not modelled)
             elif op in ("s_add_u32", "s_sub_u32", "s_addc_u32") and re.fullmatch(r"s\d+", args[0]):
                 a, b = self.sval(args[1]), self.sval(args[2])
                 r = a + b + (1 if op == "s_addc_u32" and self.scc else 0) if op != "s_sub_u32" else a - b
