@@ -383,13 +383,14 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
     const long long items = (long long)vfi::ceil_div(a.W, T::TW) * vfi::ceil_div(a.H, T::TH) * N * (a.Cout_pad / T::BN);
     if (items >= (1ll << 28)) return false;
     if (mode == 2) return true;
-    // Measured per layer of the 1080p frame against the F(2x2) kernel (twice as many, shorter items; K split) on a part
-    // with 256 CUs, i.e. 256 resident workgroups: 8-20 % faster from 7.8 rounds of items up (2000) and where the items
-    // fill whole rounds (1020 and 1530 items = 4 and 6 rounds; 216..510 = one or two), slower where the last round is
-    // mostly empty (272, 544, 816 items), between 6.25 and 7.8 rounds and at 3.4 rounds (1632 and 864 items: re-measured
-    // in round 3 with a pure "last round >= 84 % full" rule, +1.1 ms per frame) and for 6 -> 32 layers.  The windows are
-    // kept as measured, in units of rounds of the device's own CU count instead of item counts of that one part.
-    if (a.Cin < 16) return false;
+    // Which of the two Winograd kernels is faster for this layer: a cost model of both, in microseconds, fitted to the
+    // per-layer A/B of every 3x3 layer of the 1080p frame (profiles/r04_conv_layers.md: for each of the 67 shapes it picks the
+    // measured winner, or a kernel within 5 % of it).  Both kernels are persistent: time = rounds of resident workgroups x
+    // time of one work item (chunks of 4 input channels + epilogue).
+    //   F(4x4), M = 32 (vfi_conv_winograd4m.hip): 16 x 64 x 32-channel items, one workgroup per CU, 1.55 us per chunk
+    //     (3400 cycles: 72 MFMAs + 72 packed transform operations + requests) + 5 us per item (output transform, stores);
+    //   F(2x2) (vfi_conv_winograd.hip): 8 x 32 x 32-channel items, two workgroups per CU, 1.1 us per chunk + 2.7 us per item,
+    //     and its K split for few, long items (same rule as launch_winograd).
     static int cus_dev[vfi::kMaxDevices] = {};
     int &cus = cus_dev[vfi::current_device()];
     if (!cus) {
@@ -397,10 +398,20 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cus = n;
     }
-    const long long rounds = (items + cus - 1) / cus;
-    const bool full_rounds = items * 100 >= rounds * cus * 84;
-    const long long r1000 = items * 1000 / cus;                  // rounds x 1000
-    return r1000 >= 7800 || (r1000 >= 3900 && r1000 < 6250) || (r1000 <= 2000 && r1000 >= 780 && full_rounds);
+    const int nchunks = vfi::ceil_div(a.Cin, T::CK), cb = a.Cout_pad / T::BN;
+    const double cost4 = (double)((items + cus - 1) / cus) * (1.55 * nchunks + 5.0);
+    const long long items2 = (long long)vfi::ceil_div(a.W, 32) * vfi::ceil_div(a.H, 8) * N * cb, resident2 = 2ll * cus;
+    const long long out_floats = (long long)N * a.Cout * a.H * a.W;
+    auto cost2 = [&](int S) {
+        const double rounds = (double)((items2 * S + resident2 - 1) / resident2);
+        const double reduce = S > 1 ? 4.0 + (double)(S + 1) * out_floats * 4.0 / 2.5e6 : 0.0;
+        return rounds * (1.1 * nchunks / S + 2.7) + reduce;
+    };
+    double best2 = cost2(1);
+    if (a.ws && nchunks >= 16 && items2 < 4 * resident2)
+        for (int S = 2; S <= 16; S *= 2)
+            if (nchunks / S >= 8 && out_floats * S <= a.ws_floats && cost2(S) < best2) best2 = cost2(S);
+    return cost4 < best2;
 }
 
 int vfi::conv::launch_winograd4(const ConvArgs &a, int N, hipStream_t s) {
