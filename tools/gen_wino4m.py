@@ -28,14 +28,14 @@ NBUF = 4
 
 # ---- register map (VGPR numbers) -------------------------------------------------------------------------------------
 TMP = [58, 60, 62, 64]          # column-pass temporaries: four even-aligned register PAIRS (v58..v65)
-RPK = [52, 54, 56]              # packed row pass: three pairs of its own (v52..v57), so that it can interleave with a column pass
+RPK = TMP[:3]                   # packed row pass: shares the pairs (passes run as whole blocks, never interleaved)
 RTMP = [64, 65]                 # (unpacked variant: row-pass temporaries)
 PADDR, WADDR = 66, 67           # LDS byte addresses of this chunk's reads (patch / weights)
 TSET = [68, 104]                # patch sets A, B: row r at base + 6 r (6 registers)
 UBASE = 140                     # u[h][g] (4 positions of group g, 16-channel half h) at UBASE + 4 (9 h + g)
 VBUF = [212, 218]               # V rows: buffer 0 / 1 (6 registers each)
 ACCV = 224                      # accumulators 64..71 (VGPRs); 0..63 are a[0:255]
-FIRST_FREE = 52                 # the compiler keeps to v0 .. v51 inside the chunk loop
+FIRST_FREE = 58                 # the compiler keeps to v0 .. v57 inside the chunk loop
 # ---- pinned SGPRs: the request cursor lives in the body (its per-chunk arithmetic runs in the MFMAs' shadow) ----------
 S_RIN, S_RW, S_DMA, S_RD = 76, 80, 84, 85      # s[76:79] input descriptor, s[80:83] weight descriptor, LDS slot of the requests / reads
 
@@ -414,7 +414,7 @@ def gen_body(P, pending_in, first=False):
         # the two costs).  Inside a block two INDEPENDENT passes alternate instruction by instruction -- a row pass of this
         # chunk and a piece of the next chunk's column pass -- so that a packed operation's result is not needed by the very
         # next instruction.  W4M_MIX=0: passes as separate blocks (A/B).
-        mix = os.environ.get("W4M_MIX", "1") != "0"
+        mix = False         # (measured: interleaving a row pass with a column pass inside a block gains 1 % and costs six registers)
         rows = [row_pass_pk(cur, i + 1, VBUF[(i + 1) % 2]) for i in range(5)]
         cols = [op for jj in range(3) for op in column_pass_pk(nxt, 2 * jj)]
         at(13, (lambda: border_fixup(em, nxt)), 2)
@@ -512,7 +512,7 @@ def operands_macro(kind):
         outs.append('"=&{v%d}"(ST.tmp[%d])' % (r, k))
     outs.append('"+{s%d}"(ST.s_rd)' % S_RD)
     ins += ['[pa0] "v"(ST.pa0)', '[wa0] "v"(ST.wa0)', '[fixmask] "v"(ST.fixmask)', '[s_rflags] "s"(ST.s_rflags)',
-            '[s_wave] "s"(ST.s_wave)'] + (['[k5] "v"(ST.k5)', '[k41] "v"(ST.k41)'] if PK else ['[s_five] "s"(ST.s_five)'])
+            '[s_wave] "s"(ST.s_wave)'] + (['[k5] "s"(ST.k5)', '[k41] "s"(ST.k41)'] if PK else ['[s_five] "s"(ST.s_five)'])
     if kind != "prime":
         outs += ['"+{s[%d:%d]}"(ST.rin)' % (S_RIN, S_RIN + 3), '"+{s[%d:%d]}"(ST.rw)' % (S_RW, S_RW + 3), '"+{s%d}"(ST.s_dma)' % S_DMA]
         ins += ['[wvoff] "v"(ST.wvoff)'] + ['[voff%d] "v"(ST.voff[%d])' % (t, t) for t in range(5)]
