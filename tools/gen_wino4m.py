@@ -37,6 +37,7 @@ VBUF = [212, 218]               # V rows: buffer 0 / 1 (6 registers each)
 ACCV = 224                      # accumulators 64..71 (VGPRs); 0..63 are a[0:255]
 FIRST_FREE = 58                 # the compiler keeps to v0 .. v57 inside the chunk loop
 # ---- pinned SGPRs: the request cursor lives in the body (its per-chunk arithmetic runs in the MFMAs' shadow) ----------
+S_K5, S_K41 = 86, 88                            # s[86:87] = (5, 5), s[88:89] = (4, 1): written at the head of every statement
 S_RIN, S_RW, S_DMA, S_RD = 76, 80, 84, 85      # s[76:79] input descriptor, s[80:83] weight descriptor, LDS slot of the requests / reads
 
 
@@ -181,13 +182,13 @@ def column_pass_pk(s, j):
     P = pair
     two = lambda r: [r, r + 1]
     ops = [
-        ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(C), P(x[2]), P(x[4])), two(x[2]) + two(x[4]), two(C)),
+        ("v_pk_fma_f32 %s, s[86:87], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(C), P(x[2]), P(x[4])), two(x[2]) + two(x[4]), two(C)),
         ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1]" % (P(x[0]), P(x[0]), P(C)), two(x[0]) + two(C), two(x[0])),
         ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(A), P(x[2]), P(x[4])), two(x[2]) + two(x[4]), two(A)),
         ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(B), P(x[1]), P(x[3])), two(x[1]) + two(x[3]), two(B)),
         ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(C), P(x[4]), P(x[2])), two(x[4]) + two(x[2]), two(C)),
         ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(D), P(x[3]), P(x[1])), two(x[3]) + two(x[1]), two(D)),
-        ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(x[5]), P(x[3]), P(x[5])), two(x[3]) + two(x[5]), two(x[5])),
+        ("v_pk_fma_f32 %s, s[86:87], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(x[5]), P(x[3]), P(x[5])), two(x[3]) + two(x[5]), two(x[5])),
         ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1]" % (P(x[5]), P(x[1]), P(x[5])), two(x[1]) + two(x[5]), two(x[5])),
         ("v_pk_add_f32 %s, %s, %s" % (P(x[1]), P(A), P(B)), two(A) + two(B), two(x[1])),
         ("v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (P(x[2]), P(A), P(B)), two(A) + two(B), two(x[2])),
@@ -205,11 +206,11 @@ def row_pass_pk(s, i, vb):
     P = pair
     two = lambda r: [r, r + 1]
     ops = [
-        ("v_pk_fma_f32 %s, %%[k5], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(I), P(x23), P(x45)), two(x23) + two(x45), two(I)),          # (-5 x2 + x4, -5 x3 + x5)
+        ("v_pk_fma_f32 %s, s[86:87], %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(I), P(x23), P(x45)), two(x23) + two(x45), two(I)),          # (-5 x2 + x4, -5 x3 + x5)
         ("v_pk_fma_f32 %s, 4.0, %s, %s op_sel_hi:[0,1,1]" % (P(O0), P(x01), P(I)), two(x01) + two(I), two(O0)),                                           # (v0, v5)
-        ("v_pk_fma_f32 %s, %%[k41], %s, %s op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(PR), P(x23), P(x45)),
+        ("v_pk_fma_f32 %s, s[88:89], %s, %s op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(PR), P(x23), P(x45)),
          two(x23) + two(x45), two(PR)),                                                                                                    # (p, r) = (x4 - 4 x2, x4 - x2)
-        ("v_pk_fma_f32 %s, %%[k41], %s, %s op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(QS), P(x01), P(x23)),
+        ("v_pk_fma_f32 %s, s[88:89], %s, %s op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (P(QS), P(x01), P(x23)),
          two(x01) + two(x23), two(QS)),                                                                                                    # (q, s) = (x3 - 4 x1, x3 - x1)
         ("v_pk_add_f32 %s, %s, %s op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" % (P(O1), P(PR), P(QS)), two(PR) + two(QS), two(O1)),         # (v1, v2) = (p + q, p - q)
         ("v_pk_fma_f32 %s, 2.0, %s, %s op_sel:[0,1,1] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" % (P(O2), P(QS), P(PR)), two(QS) + two(PR), two(O2)),   # (v3, v4) = (2 s + r, -2 s + r)
@@ -273,6 +274,17 @@ def patch_reads(em, s):
 
 def weight_read(em, h, g):
     em.ds_read(128, UBASE + 4 * (9 * h + g), WADDR, (g * BN + h * 16) * 16)
+
+
+def const_setup(em):
+    """5.0 and the pair (4, 1) of the packed transforms: two scalar moves each at the head of the statement instead of four
+    scalar registers that live across the whole loop (the kernel is short of them: every one that spills costs a
+    v_readlane per chunk)."""
+    if PK:
+        em.raw("s_mov_b32 s%d, 0x40a00000" % S_K5)
+        em.raw("s_mov_b32 s%d, 0x40a00000" % (S_K5 + 1))
+        em.raw("s_mov_b32 s%d, 0x40800000" % S_K41)
+        em.raw("s_mov_b32 s%d, 0x3f800000" % (S_K41 + 1))
 
 
 def addr_setup(em):
@@ -344,6 +356,7 @@ def gen_prime():
     """Before the first chunk: chunk 0 has landed -> patch set 0 and the weights into registers, column pass, row 0."""
     em = Emitter()
     five = "%[s_five]"
+    const_setup(em)
     addr_setup(em)
     entry_wait(em, 3)
     patch_reads(em, 0)
@@ -460,6 +473,7 @@ def gen_body(P, pending_in, first=False):
     at(30, (lambda: read_cursor_step(em)), 1)             # (after the statement's last use of the read slot: its address setup)
 
     # ---- emit ----
+    const_setup(em)
     addr_setup(em)
     for m, (i, j, h) in enumerate(order):
         em.mfma(h, 6 * i + j, vreg(VBUF[i % 2], j), first)
@@ -512,7 +526,9 @@ def operands_macro(kind):
         outs.append('"=&{v%d}"(ST.tmp[%d])' % (r, k))
     outs.append('"+{s%d}"(ST.s_rd)' % S_RD)
     ins += ['[pa0] "v"(ST.pa0)', '[wa0] "v"(ST.wa0)', '[fixmask] "v"(ST.fixmask)', '[s_rflags] "s"(ST.s_rflags)',
-            '[s_wave] "s"(ST.s_wave)'] + (['[k5] "s"(ST.k5)', '[k41] "s"(ST.k41)'] if PK else ['[s_five] "s"(ST.s_five)'])
+            '[s_wave] "s"(ST.s_wave)'] + ([] if PK else ['[s_five] "s"(ST.s_five)'])
+    if PK:
+        outs += ['"=&{s[%d:%d]}"(ST.k5)' % (S_K5, S_K5 + 1), '"=&{s[%d:%d]}"(ST.k41)' % (S_K41, S_K41 + 1)]
     if kind != "prime":
         outs += ['"+{s[%d:%d]}"(ST.rin)' % (S_RIN, S_RIN + 3), '"+{s[%d:%d]}"(ST.rw)' % (S_RW, S_RW + 3), '"+{s%d}"(ST.s_dma)' % S_DMA]
         ins += ['[wvoff] "v"(ST.wvoff)'] + ['[voff%d] "v"(ST.voff[%d])' % (t, t) for t in range(5)]

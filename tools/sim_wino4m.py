@@ -115,6 +115,9 @@ class Wave:
                 assert n == 2 and d % 2 == 0, ln
 
                 def half(tok, sel):
+                    ms = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+                    if ms:                                             # scalar pair written by the statement's own s_mov
+                        return np.full(64, np.float64(np.array([self.s[int(ms.group(1)) + sel]], np.uint32).view(np.float32)[0]))
                     if re.fullmatch(r"-?\d+\.\d+", tok):             # inline constant: low half only
                         return np.full(64, np.float64(float(tok)) if sel == 0 else 0.0)
                     if tok.startswith("%["):
