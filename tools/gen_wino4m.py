@@ -512,6 +512,11 @@ def operands_macro(kind):
         tset(0, '"=&{v[%d:%d]}"(ST.t_lo[%d][%d])', '"=&{v[%d:%d]}"(ST.t_hi[%d][%d])', outs)
         uc = '"=&{v[%d:%d]}"(ST.u[%d])'
         vc = ['"=&{v[%d:%d]}"(ST.vb[%d])'] * 3
+    elif kind == "loop":                                     # pairs of chunks: set 0 comes in and goes out, set 1 is scratch
+        tset(0, '"+{v[%d:%d]}"(ST.t_lo[%d][%d])', '"+{v[%d:%d]}"(ST.t_hi[%d][%d])', outs)
+        tset(1, '"=&{v[%d:%d]}"(ST.t_lo[%d][%d])', '"=&{v[%d:%d]}"(ST.t_hi[%d][%d])', outs)
+        uc = '"+{v[%d:%d]}"(ST.u[%d])'
+        vc = ['"+{v[%d:%d]}"(ST.vb[%d])', '"+{v[%d:%d]}"(ST.vb[%d])', '"=&{v[%d:%d]}"(ST.vb[%d])']
     else:
         tset(1 - kind, '"=&{v[%d:%d]}"(ST.t_lo[%d][%d])', '"=&{v[%d:%d]}"(ST.t_hi[%d][%d])', outs)
         tset(kind, '"{v[%d:%d]}"(ST.t_lo[%d][%d])', '"{v[%d:%d]}"(ST.t_hi[%d][%d])', ins)
@@ -529,11 +534,13 @@ def operands_macro(kind):
             '[s_wave] "s"(ST.s_wave)'] + ([] if PK else ['[s_five] "s"(ST.s_five)'])
     if PK:
         outs += ['"=&{s[%d:%d]}"(ST.k5)' % (S_K5, S_K5 + 1), '"=&{s[%d:%d]}"(ST.k41)' % (S_K41, S_K41 + 1)]
+    if kind == "loop":
+        outs.append('[s_n] "+s"(ST.s_n)')
     if kind != "prime":
         outs += ['"+{s[%d:%d]}"(ST.rin)' % (S_RIN, S_RIN + 3), '"+{s[%d:%d]}"(ST.rw)' % (S_RW, S_RW + 3), '"+{s%d}"(ST.s_dma)' % S_DMA]
         ins += ['[wvoff] "v"(ST.wvoff)'] + ['[voff%d] "v"(ST.voff[%d])' % (t, t) for t in range(5)]
         outs.append('[s_wt] "=&s"(ST.s_wt)')
-        ins += ['[s_first] "s"(ST.s_first)', '[s_inc] "s"(ST.s_inc)', '[s_winc] "s"(ST.s_winc)', '[s_dma_end] "s"(ST.s_dma_end)',
+        ins += ([] if kind == "loop" else ['[s_first] "s"(ST.s_first)']) + ['[s_inc] "s"(ST.s_inc)', '[s_winc] "s"(ST.s_winc)', '[s_dma_end] "s"(ST.s_dma_end)',
                 '[s_w0] "s"(ST.s_w[0])', '[s_wstep] "s"(ST.s_wstep)']
     return outs, ins
 
@@ -574,7 +581,11 @@ def main(out_path):
         both = lambda normal, first: ["s_cmp_lg_u32 %[s_first], 0", "s_cbranch_scc1 8f"] + normal + ["s_branch 9f", "8:"] + first + ["9:"]
         f.write("#define W4M_ASM_BODY0 \\\n" + c_string(both(b0, b0f)).replace("\n", " \\\n") + "\n")
         f.write("#define W4M_ASM_BODY1 \\\n" + c_string(both(b1, b1f)).replace("\n", " \\\n") + "\n")
-        for kind, tag in (("prime", "PRIME"), (0, "BODY0"), (1, "BODY1"), ("drain", "DRAIN"), ("zero", "ZERO")):
+        # %[s_n] PAIRS of chunks (parity 0 then 1) of one item with no item boundary on any of the three cursors: the whole
+        # loop control is two scalar instructions, where the compiler's code between two statements costs ~300 idle cycles
+        loop = ["Lw4m_loop_%=:"] + b0 + b1 + ["s_sub_u32 %[s_n], %[s_n], 1", "s_cmp_lg_u32 %[s_n], 0", "s_cbranch_scc1 Lw4m_loop_%="]
+        f.write("#define W4M_ASM_LOOP \\\n" + c_string(loop).replace("\n", " \\\n") + "\n")
+        for kind, tag in (("prime", "PRIME"), (0, "BODY0"), (1, "BODY1"), ("loop", "LOOP"), ("drain", "DRAIN"), ("zero", "ZERO")):
             outs, ins = operands_macro(kind)
             f.write("#define W4M_OPERANDS_%s(ST) \\\n    : " % tag + ", \\\n      ".join(outs) + " \\\n    : " + ", \\\n      ".join(ins) + "\n")
     return prime, b0, b1, b0f, b1f

@@ -20,7 +20,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # source file of each kernel: bench.py only reports the traffic while the tree still holds the source the counters were taken on
-KERNEL_SOURCES = {"conv3x3_winograd4_kernel": "vfi_conv_winograd4.hip", "conv3x3_winograd_kernel": "vfi_conv_winograd.hip"}
+KERNEL_SOURCES = {"conv3x3_winograd4m_kernel": "vfi_conv_winograd4m.hip", "conv3x3_winograd4_kernel": "vfi_conv_winograd4.hip",
+                  "conv3x3_winograd_kernel": "vfi_conv_winograd.hip"}
 
 
 def source_hash(label):
@@ -30,7 +31,8 @@ def source_hash(label):
 csv.field_size_limit(sys.maxsize)
 
 # kernels whose global reads are 16-B-per-lane streams (FETCH_SIZE x 2); label -> substring of the kernel name
-WIDE_READERS = {"conv3x3_winograd4_kernel": "conv3x3_winograd4_kernel", "conv3x3_winograd_kernel": "conv3x3_winograd_kernel"}
+WIDE_READERS = {"conv3x3_winograd4m_kernel": "conv3x3_winograd4m_kernel", "conv3x3_winograd4_kernel": "conv3x3_winograd4_kernel<",
+                "conv3x3_winograd_kernel": "conv3x3_winograd_kernel"}
 
 
 def collect(directory, counter):

@@ -4,7 +4,7 @@
 # Every step appends to gpurun_out/refresh.log so a long run never looks silent.
 set -e
 cd "${GRAFT_REPO_ROOT:-.}"
-R=r03
+R=r04
 mkdir -p gpurun_out
 log() { echo "[$(date +%T)] $*" | tee -a gpurun_out/refresh.log; }
 export TMPDIR=/tmp
@@ -17,11 +17,25 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof3 -o p3 -
 cp "$(find gpurun_out/prof1 -name '*kernel_stats.csv' | head -1)" gpurun_out/${R}_bench_streams1_kernel_stats.csv
 cp "$(find gpurun_out/prof3 -name '*kernel_stats.csv' | head -1)" gpurun_out/${R}_bench_default_kernel_stats.csv
 find gpurun_out/prof3 gpurun_out/prof1 -name "*kernel_trace.csv" -delete
+cp "$(find gpurun_out/prof1 -name '*kernel_stats.csv' | head -1)" gpurun_out/${R}_bench_streams1_kernel_stats.csv
 log "PMC passes (separate runs, counters only): FETCH_SIZE, WRITE_SIZE"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --streams 1 --steps-720p 0 --no-profile > /dev/null 2>> gpurun_out/refresh.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --streams 1 --steps-720p 0 --no-profile > /dev/null 2>> gpurun_out/refresh.log
 python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --out gpurun_out/${R}_traffic.json \
     --command "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --streams 1 --steps-720p 0 --no-profile" >> gpurun_out/refresh.log
+# (the raw counter rows of the dominant kernel stay, so that the digest can be recomputed: VERDICT r03 item 6)
+for d in fetch write; do python3 - "$d" <<'PY'
+import csv, glob, sys
+d = sys.argv[1]
+src = glob.glob(f"gpurun_out/pmc_{d}/**/*counter_collection.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(src)) if "conv3x3_winograd4m_kernel" in r["Kernel_Name"]]
+keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"]
+with open(f"gpurun_out/r04_traffic_{d}_rows.csv", "w", newline="") as f:
+    w = csv.DictWriter(f, keep); w.writeheader()
+    for r in rows:
+        r = {k: r[k] for k in keep}; r["Kernel_Name"] = r["Kernel_Name"].split("(")[0][-60:]; w.writerow(r)
+PY
+done
 find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*counter_collection.csv" -delete
 log "pyramid kernels"
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pyrprof -o pp -- python3 tools/pyramid_bench.py > gpurun_out/${R}_pyramid_bench_under_rocprof.txt 2>> gpurun_out/refresh.log
