@@ -384,7 +384,7 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
     if (items >= (1ll << 28)) return false;
     if (mode == 2) return true;
     // Which of the two Winograd kernels is faster for this layer: a cost model of both, in microseconds, fitted to the
-    // per-layer A/B of every 3x3 layer of the 1080p frame (profiles/r04_conv_layers.md: for each of the 67 shapes it picks the
+    // per-layer A/B of every 3x3 layer of the 1080p frame (profiles/r04_conv_layers.txt: for each of the 67 shapes it picks the
     // measured winner, or a kernel within 5 % of it).  Both kernels are persistent: time = rounds of resident workgroups x
     // time of one work item (chunks of 4 input channels + epilogue).
     //   F(4x4), M = 32 (vfi_conv_winograd4m.hip): 16 x 64 x 32-channel items, one workgroup per CU, 1.55 us per chunk
