@@ -164,11 +164,12 @@ def spawn_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # per-rank logs (the ranks' output still streams to this console, prefixed with its rank): when a rank fails, the
-    # launcher's summary names it, and the stderr of the rank that failed FIRST is repeated below it
+    # per-rank stderr logs (stderr still streams to this console, prefixed with its rank; stdout -- rank 0's ONE JSON line --
+    # is left alone): when a rank fails, the launcher's summary names it, and the stderr of the rank that failed FIRST is
+    # repeated below it
     import tempfile
     with tempfile.TemporaryDirectory(prefix="vfi_bench_logs_") as logs:
-        cmd[3:3] = ["--log-dir", logs, "--tee", "3"]
+        cmd[3:3] = ["--log-dir", logs, "--tee", "2"]
         rc = subprocess.call(cmd, env=env)
         if rc != 0:
             rank, tail = first_failing_rank_log(logs)
