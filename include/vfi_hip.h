@@ -17,7 +17,7 @@
  *     Workspace is caller-provided or owned by an explicit plan object.
  *   - Process-wide state is limited to idempotent per-device launch setup (the dynamic-LDS
  *     attribute of three kernels, the CU count), tuning switches read once from the
- *     environment (VFI_CONV_WINOGRAD, VFI_CONV_WINOGRAD4, VFI_ADACOF_VARIANT, VFI_ADACOF_MARGIN) and the
+ *     environment (VFI_CONV_WINOGRAD, VFI_CONV_WINOGRAD4, VFI_ADACOF_VARIANT, VFI_ADACOF_MARGIN; VFI_CONV_WINOGRAD4M at every call) and the
  *     thread-local last-error string; everything else lives in explicit plan objects,
  *     whose tables are immutable after creation and whose workspace belongs to ONE stream
  *     at a time (frames in flight on different streams use different plans).
@@ -131,13 +131,15 @@ int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int 
  * Replaces every nn.Conv2d (+ following BatchNorm / ReLU / ELU / Tanh / Sigmoid, + the additive U-Net
  * skip) on the path: reference src/phase_net/phase_net.py:190-200, src/fusion_net/fusion_adacofnet.py:18-155,
  * src/fusion_net/fusion_net.py:24-41,56-69.
- * KS = 3 runs Winograd on the fp32 matrix cores -- F(2x2,3x3), and F(4x4,3x3) for plain layers with Cin >= 16 whose work
- * items (16x64 output tiles x 32-channel blocks) keep one workgroup per CU busy to the end: 7.8 or more rounds of the
- * device's CU count, 3.9-6.25 rounds, or at most two rounds with the last one at least 84 % full (the windows measured
- * per layer; vfi_conv2d_algo tells which kernel a layer gets; same result up to fp32 rounding
- * of the transforms: rms 3e-7 resp. 2e-6 of the output rms,
- * <= 3e-5 resp. 1e-4 at worst on O(1) data; VFI_CONV_WINOGRAD4=0 in the environment keeps F(2x2) everywhere,
- * VFI_CONV_WINOGRAD=0 selects the direct kernel), KS = 1 / 5 the direct one.
+ * KS = 3 runs Winograd on the fp32 matrix cores -- F(4x4,3x3) (16x64-pixel x 32-channel work items, one workgroup per
+ * CU) or F(2x2,3x3) (8x32-pixel items, two per CU, K split for few long items), whichever a cost model of the two kernels
+ * (rounds of resident workgroups x time per item, fitted to a per-layer A/B of the 1080p frame) puts ahead;
+ * vfi_conv2d_algo tells which kernel a layer gets; same result up to fp32 rounding of the transforms: rms 3e-7 resp.
+ * 2e-6 of the output rms, <= 3e-5 resp. 1e-4 at worst on unit-variance data (2.5e-4 on the statistics of trained PhaseNet
+ * weights with folded BatchNorm).  Environment (A/B aids): VFI_CONV_WINOGRAD4=0 keeps F(2x2) everywhere, =2 sends every
+ * plain 3x3 layer to F(4x4); VFI_CONV_WINOGRAD4M=0 (read at every call) runs F(4x4) on round 3's kernel -- 16 channels per
+ * wave, two waves per SIMD; bit-identical outputs -- instead of the 32-channel-per-wave one; VFI_CONV_WINOGRAD=0 selects
+ * the direct kernel.  KS = 1 / 5: the direct one.
  *   x        (N, Cin, H, W); consecutive samples are x_bstride floats apart, so x may be a channel
  *            slice of a wider tensor (no concat / split copies)
  *   residual NULL or (N, Cout, H, W) with stride res_bstride, added AFTER the activation
