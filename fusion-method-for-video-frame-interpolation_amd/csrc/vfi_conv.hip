@@ -509,6 +509,7 @@ static int conv2d_impl(const float *x, long long x_bstride, const float *packed_
 // place the selection lives is here, next to the dispatch above).
 extern "C" int vfi_conv2d_algo(int N, int Cin, int H, int W, int Cout, int KS, int has_residual, int pooled, int act) {
     if (N < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return VFI_ERR_INVALID_ARG;
+    if (KS != 1 && KS != 3 && KS != 5) return VFI_ERR_UNSUPPORTED;      // what vfi_conv2d answers for the same layer
     static const bool wino_on = !(getenv("VFI_CONV_WINOGRAD") && atoi(getenv("VFI_CONV_WINOGRAD")) == 0);
     ConvArgs a{};
     a.Cin = Cin; a.Cout = Cout; a.Cout_pad = round_up(Cout, 32); a.H = H; a.W = W; a.act = act; a.tiles_x = vfi::ceil_div(W, 32);

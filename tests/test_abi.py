@@ -68,15 +68,21 @@ def test_no_cpu_fallback():
 
 
 def test_conv_algorithm_query_reports_the_library_rule():
-    """vfi_conv2d_algo is the one place the convolution selection lives (profiling labels query it instead of restating
-    it).  Without a GPU the library assumes 256 CUs, the part the windows were measured on: the query must reproduce them."""
-    h = vfi_amd.lib()
-    direct, wino2, wino4 = 0, 1, 2
-    assert h.vfi_conv2d_algo(1, 32, 1088, 1920, 3, 5, 0, 0, 1) == direct          # 5x5: direct implicit GEMM
-    assert h.vfi_conv2d_algo(1, 64, 1088, 1920, 64, 1, 0, 0, 0) == direct         # 1x1
-    assert h.vfi_conv2d_algo(3, 64, 544, 960, 64, 3, 0, 0, 1) == wino4            # 3060 items: >= 7.8 rounds of 256 CUs
-    assert h.vfi_conv2d_algo(1, 6, 1088, 1920, 32, 3, 0, 0, 1) == wino2           # Cin < 16
-    assert h.vfi_conv2d_algo(3, 128, 272, 480, 128, 3, 0, 0, 1) == wino2          # 1632 items: 6.4 rounds, between the windows
-    assert h.vfi_conv2d_algo(1, 64, 544, 960, 64, 3, 0, 0, 1) == wino4            # 1020 items: four full rounds
-    assert h.vfi_conv2d_algo(1, 128, 272, 480, 128, 3, 0, 0, 1) == wino2          # 544 items: last round mostly empty
-    assert h.vfi_conv2d_algo(0, 64, 64, 64, 64, 3, 0, 0, 1) < 0                   # bad arguments: a status, not an algorithm
+    """vfi_conv2d_algo (no GPU call): which kernel a layer gets -- the library's cost model of the two Winograd kernels
+    (csrc/vfi_conv_winograd4.hip: winograd4_suits, fitted to profiles/r04_conv_layers.txt), mirrored nowhere else.  The
+    expectations are measured winners of that table (256-CU default)."""
+    from vfi_amd import _lib
+    algo = _lib.lib().vfi_conv2d_algo
+    ELU, RELU = 2, 1
+    assert algo(3, 64, 1080, 1920, 64, 3, 0, 0, ELU) == 2          # PhaseNet level 7: 12240 items of 16 chunks -> F(4x4)
+    assert algo(3, 88, 1080, 1920, 64, 3, 1, 0, ELU) == 2          # ... with a residual: still F(4x4) (RES instantiation)
+    assert algo(1, 6, 1088, 1920, 32, 3, 0, 0, RELU) == 2          # first U-Net layer: 2 chunks per item, 8 rounds: F(4x4) by 20 %
+    assert algo(3, 256, 136, 240, 256, 3, 0, 0, RELU) == 2         # 864 items (3.4 rounds) of 64 chunks: F(4x4) by 17 %
+    assert algo(1, 128, 136, 240, 128, 3, 0, 0, RELU) == 2         # 144 items, one round: F(4x4) by 19 %
+    assert algo(1, 64, 272, 480, 64, 3, 0, 0, RELU) == 1           # 272 items = 1.06 rounds: the second round is empty -> F(2x2)
+    assert algo(1, 512, 34, 60, 512, 3, 0, 0, RELU) == 1           # 48 long items: F(2x2) with its K split
+    assert algo(3, 64, 68, 120, 64, 3, 0, 0, ELU) == 1             # small PhaseNet level
+    assert algo(1, 32, 1088, 1920, 32, 3, 0, 1, RELU) == 2         # pooled ReLU layer: F(4x4) POOL instantiation
+    assert algo(1, 32, 1088, 1920, 32, 3, 0, 1, ELU) == 1          # pooled non-ReLU: only the F(2x2) path pools in the epilogue
+    assert algo(1, 18, 1080, 1920, 32, 5, 0, 0, RELU) == 0 and algo(3, 64, 1080, 1920, 8, 1, 0, 0, 3) == 0
+    assert algo(0, 64, 16, 16, 64, 3, 0, 0, 0) < 0 and algo(1, 64, 16, 16, 64, 4, 0, 0, 0) < 0
