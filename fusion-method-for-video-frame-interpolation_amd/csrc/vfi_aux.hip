@@ -193,6 +193,17 @@ __global__ __launch_bounds__(256) void resize_bilinear_tile_kernel(const float *
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
             *reinterpret_cast<float4 *>(y + (size_t)n * y_bs + o) = v;
+        } else if (xo0 + 3 < Wo) {
+            // rows of a width that is no multiple of four (the 1358- and 679-pixel pyramid levels): still one 16-byte store
+            // per thread -- the memory pipeline needs 4-byte alignment only, which the compiler cannot be told through a
+            // float4 pointer
+            if (res) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[k] += res[(size_t)n * res_bs + o + k];
+            }
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 v = {out[0], out[1], out[2], out[3]};
+            asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(y + (size_t)n * y_bs + o), "v"(v) : "memory");
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
