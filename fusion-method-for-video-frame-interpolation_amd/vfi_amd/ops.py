@@ -137,6 +137,8 @@ def conv2d(x, pc, pad_mode="zeros", act=None, residual=None, out=None, upsample2
             if pc.ks == 1:
                 # a 1x1 layer (PhaseNet's 64 -> 8 prediction maps, the coarse 1x1 blocks, FusionNet's 32 -> 3 tail) does
                 # 2*Cout flop per input byte: it is bound by reading the input once, not by the matrix cores
+                if _lib.lib().vfi_conv2d_algo(n, cin, h, w, pc.cout, 1, int(residual is not None), 0, ACT[act]) == 3:
+                    label = "conv1x1_stream_kernel"
                 work = ("byte", 4.0 * n * (cin + pc.cout) * h * w, label)
     _lib.call("vfi_conv2d_upsample2x" if upsample2x else "vfi_conv2d", xp, xs, pc.packed.data_ptr(), pc.bias.data_ptr(), rp, rs, yp, ys,
               n, cin, h, w, pc.cout, pc.ks, PAD[pad_mode], ACT[act], ws.data_ptr(), ws.numel(), _lib.stream_ptr(), work=work)

@@ -149,10 +149,11 @@ int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int 
  *            loop is split over several workgroups whose partial sums go through the workspace and are reduced
  *            in a fixed order (deterministic).  16 * N*Cout*H*W floats always suffice; results do not depend on
  *            whether a workspace is given beyond fp32 summation order. */
-enum { VFI_CONV_ALGO_DIRECT = 0, VFI_CONV_ALGO_WINOGRAD2 = 1, VFI_CONV_ALGO_WINOGRAD4 = 2 };
+enum { VFI_CONV_ALGO_DIRECT = 0, VFI_CONV_ALGO_WINOGRAD2 = 1, VFI_CONV_ALGO_WINOGRAD4 = 2, VFI_CONV_ALGO_STREAM1X1 = 3 };
 /* Which kernel vfi_conv2d / vfi_conv2d_pool2 runs for a layer on the current device (>= 0: VFI_CONV_ALGO_*; < 0: status):
- * direct implicit GEMM, Winograd F(2x2,3x3) or Winograd F(4x4,3x3).  For profiling labels and flop counts: the
- * selection rule lives in the library only. */
+ * direct implicit GEMM, Winograd F(2x2,3x3), Winograd F(4x4,3x3), or the streaming kernel of 1x1 layers with at most 16 output
+ * channels (an even number of >= 4096 pixels, no residual; operands assumed 8-byte aligned).  For profiling labels and flop
+ * counts: the selection rule lives in the library only. */
 int vfi_conv2d_algo(int N, int Cin, int H, int W, int Cout, int KS, int has_residual, int pooled, int act);
 
 int vfi_conv2d(const float *x, long long x_bstride, const float *packed_w, const float *bias,

@@ -84,5 +84,8 @@ def test_conv_algorithm_query_reports_the_library_rule():
     assert algo(3, 64, 68, 120, 64, 3, 0, 0, ELU) == 1             # small PhaseNet level
     assert algo(1, 32, 1088, 1920, 32, 3, 0, 1, RELU) == 2         # pooled ReLU layer: F(4x4) POOL instantiation
     assert algo(1, 32, 1088, 1920, 32, 3, 0, 1, ELU) == 1          # pooled non-ReLU: only the F(2x2) path pools in the epilogue
-    assert algo(1, 18, 1080, 1920, 32, 5, 0, 0, RELU) == 0 and algo(3, 64, 1080, 1920, 8, 1, 0, 0, 3) == 0
+    assert algo(1, 18, 1080, 1920, 32, 5, 0, 0, RELU) == 0 and algo(3, 64, 1080, 1920, 64, 1, 0, 0, 3) == 0
+    # 1x1 layers with <= 16 output channels on >= 4096 pixels stream (conv1x1_stream_kernel); small levels and wide layers do not
+    assert algo(3, 64, 1080, 1920, 8, 1, 0, 0, 3) == 3 and algo(1, 64, 544, 960, 9, 1, 0, 0, 0) == 3 and algo(3, 64, 382, 679, 8, 1, 0, 0, 3) == 3
+    assert algo(3, 64, 9, 15, 8, 1, 0, 0, 3) == 0 and algo(3, 64, 135, 241, 8, 1, 0, 0, 3) == 0 and algo(1, 32, 1080, 1920, 3, 1, 1, 0, 0) == 0
     assert algo(0, 64, 16, 16, 64, 3, 0, 0, 0) < 0 and algo(1, 64, 16, 16, 64, 4, 0, 0, 0) < 0

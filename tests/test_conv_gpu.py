@@ -62,6 +62,27 @@ def test_conv_matches_torch_cpu(n, cin, cout, h, w, ks, pad, act, device):
     assert err <= 2e-5, err
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,act", [(3, 64, 8, 96, 128, "tanh"), (1, 64, 1, 64, 68, "tanh"), (1, 32, 3, 80, 100, None),
+                                                (2, 70, 5, 66, 64, "elu"), (1, 7, 8, 64, 64, "relu"), (1, 64, 9, 72, 96, None),
+                                                (3, 64, 8, 74, 83, "tanh"), (2, 16, 16, 70, 61, "sigmoid")])
+def test_conv1x1_streaming_kernel_matches_torch_cpu(n, cin, cout, h, w, act, device):
+    """1x1 layers with <= 16 output channels and an even number of >= 4096 pixels take conv1x1_stream_kernel (csrc/vfi_conv.hip;
+    four pixels per thread, two where the plane size is no multiple of four; the last case -- an odd plane -- stays on the matrix cores):
+    PhaseNet's prediction maps (phase_net.py:190-207), read from and written into channel slices of the 72-channel block buffer."""
+    g = torch.Generator().manual_seed(cin * 100 + cout + h)
+    wide_in = torch.randn((n, cin + 9, h, w), generator=g)
+    wgt = torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    ref = _ref(wide_in[:, 4:4 + cin], wgt, b, 1, "zeros", act)
+    pc = ops.PackedConv(wgt, b, device=device)
+    xin = wide_in.to(device)
+    wide_out = torch.full((n, cout + 4, h, w), 7.0, device=device)
+    ops.conv2d(xin[:, 4:4 + cin], pc, "zeros", act, out=wide_out[:, 4:])
+    torch.cuda.synchronize()
+    assert (wide_out[:, 4:].cpu() - ref).abs().max().item() <= 2e-5
+    assert (wide_out[:, :4] == 7.0).all()          # the neighbouring channels of the slice are untouched
+
+
 BIG_CASES = [
     # 3x3 layers the F(4x4,3x3) Winograd kernel takes (csrc/vfi_conv_winograd4.hip: >= 2000 items of a 16x64 tile x 32 couts,
     # Cin >= 16)

@@ -33,6 +33,10 @@ tot = collections.Counter()
 for name, args, e0, e1 in rows:
     ms = e0.elapsed_time(e1)
     tot[name] += ms
+    if name == "vfi_conv2d" and "conv1x1" in want and args[13] == 1:      # 1x1 layers: bytes/s of reading the input + writing the output
+        n, cin, h, w, cout = args[8:13]
+        by = 4.0 * n * (cin + cout) * h * w
+        print(f"vfi_conv2d 1x1 {n}x{cin}->{cout} @{h}x{w}: {1e3 * ms:8.1f} us  {by / 1e6:8.1f} MB  {by / ms / 1e6:7.1f} GB/s")
     if name not in want:
         continue
     ints = [a for a in args if isinstance(a, int) and not isinstance(a, bool) and abs(a) < (1 << 24)]
