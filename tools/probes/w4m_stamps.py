@@ -20,14 +20,16 @@ for name, n, cin, cout, h, w, pad, act in cases:
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); ops.conv2d(x, pc, pad, act); e1.record(); torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * (256 * 4 * 8))()
-    assert _lib.lib().vfi_debug_w4m_stamps(buf, 256 * 4 * 8) == 0
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 4, 8).astype(np.float64)
+    buf = (ctypes.c_ulonglong * (256 * 4 * 10))()
+    assert _lib.lib().vfi_debug_w4m_stamps(buf, 256 * 4 * 10) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 4, 10).astype(np.float64)
     body, between, epi, nb, ne, total = (a[..., k] for k in range(6))
     ms = e0.elapsed_time(e1)
     print(f"{name}: {ms:.3f} ms; per wave: total {total.mean():.0f} cycles -> clock {total.mean() / ms / 1e3:.0f} MHz (if the kernel fills the launch)")
     print(f"  bodies {nb.mean():.0f} x {body.sum() / nb.sum():.0f} cycles; between bodies {between.sum() / nb.sum():.0f} cycles per body; "
           f"epilogues {ne.mean():.1f} x {epi.sum() / ne.sum():.0f} cycles; unaccounted {(total - body - between - epi).mean():.0f}")
     print(f"  inside an epilogue: accumulator reads + first pass {a[..., 6].sum() / ne.sum():.0f} cycles, second pass + bias + activation + stores {a[..., 7].sum() / ne.sum():.0f}")
+    tl, nl = a[..., 8].sum(), a[..., 9].sum()
+    print(f"  bodies inside the looping statement: {nl / a[..., 3].sum():.2f} of all, {tl / max(nl, 1):.0f} cycles each; single-chunk statements {(body.sum() - tl) / max(nb.sum() - nl, 1):.0f} cycles each")
     for wv in range(4):
         print(f"  wave {wv}: body {body[:, wv].sum() / nb[:, wv].sum():.0f} between {between[:, wv].sum() / nb[:, wv].sum():.0f} epi {epi[:, wv].sum() / ne[:, wv].sum():.0f}")
