@@ -373,6 +373,11 @@ def gen_prime():
     return em.lines, []
 
 
+# gap (MFMA index) behind which the next chunk's first column-pass block sits; the row pass of row 2 sits behind MFMA 18: with
+# 18 the two form ONE block of 18 operations (every switch between the matrix pipe and the vector ALU costs ~15 cycles)
+COLGAP = int(os.environ.get("W4M_COLGAP", "18"))
+
+
 def mfma_order():
     """(row i, column j, half h) in issue order: 12 per row of positions."""
     return [(i, j, h) for i in range(6) for j in range(6) for h in range(2)]
@@ -449,7 +454,7 @@ def gen_body(P, pending_in, first=False):
                     at(12 * i + 6, valu(text, rd, wr), 1)
             for jj in range(3):
                 for text, rd, wr in cols[12 * jj:12 * jj + 12]:
-                    at(16 + 12 * jj, valu(text, rd, wr), 1)
+                    at(COLGAP + 12 * jj, valu(text, rd, wr), 1)
         for text, rd, wr in row_pass_pk(nxt, 0, VBUF[0]):
             at(64, valu(text, rd, wr), 1)
     else:
