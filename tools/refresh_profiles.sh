@@ -8,8 +8,6 @@ R=r04
 mkdir -p gpurun_out
 log() { echo "[$(date +%T)] $*" | tee -a gpurun_out/refresh.log; }
 export TMPDIR=/tmp
-log "bench default (3 CPU runs)"
-python bench.py > gpurun_out/${R}_bench_default.json 2>> gpurun_out/refresh.log
 log "bench --streams 1 under rocprofv3 --kernel-trace --stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof1 -o p1 -- python3 bench.py --no-cpu-baseline --steps 10 --streams 1 --steps-720p 0 > gpurun_out/${R}_bench_streams1_under_rocprof.json 2>> gpurun_out/refresh.log
 log "bench default under rocprofv3 --kernel-trace --stats"
@@ -37,6 +35,10 @@ with open(f"gpurun_out/r04_traffic_{d}_rows.csv", "w", newline="") as f:
 PY
 done
 find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*counter_collection.csv" -delete
+# (the line of the default run reads roofline.traffic from profiles/: put this build's digest there first)
+cp gpurun_out/${R}_traffic.json profiles/${R}_traffic.json
+log "bench default (3 CPU runs)"
+python bench.py > gpurun_out/${R}_bench_default.json 2>> gpurun_out/refresh.log
 log "pyramid kernels"
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pyrprof -o pp -- python3 tools/pyramid_bench.py > gpurun_out/${R}_pyramid_bench_under_rocprof.txt 2>> gpurun_out/refresh.log
 python3 tools/pyr_kernel_table.py "$(find gpurun_out/pyrprof -name '*kernel_trace.csv' | head -1)" 40 > gpurun_out/${R}_pyramid_kernel_table.txt
