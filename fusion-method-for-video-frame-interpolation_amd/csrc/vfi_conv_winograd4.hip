@@ -387,8 +387,9 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
     // per-layer A/B of every 3x3 layer of the 1080p frame (profiles/r04_conv_layers.txt: for each of the 67 shapes it picks the
     // measured winner, or a kernel within 5 % of it).  Both kernels are persistent: time = rounds of resident workgroups x
     // time of one work item (chunks of 4 input channels + epilogue).
-    //   F(4x4), M = 32 (vfi_conv_winograd4m.hip): 16 x 64 x 32-channel items, one workgroup per CU, 1.55 us per chunk
-    //     (3400 cycles: 72 MFMAs + 72 packed transform operations + requests) + 5 us per item (output transform, stores);
+    //   F(4x4), M = 32 (vfi_conv_winograd4m.hip): 16 x 64 x 32-channel items, one workgroup per CU, 1.45 us per chunk
+    //     (2 930 cycles: 72 MFMAs + 72 packed transform operations + requests) + 3.8 us per item (output transform, stores,
+    //     item set-up; 5.0 before the straight-line epilogue);
     //   F(2x2) (vfi_conv_winograd.hip): 8 x 32 x 32-channel items, two workgroups per CU, 1.1 us per chunk + 2.7 us per item,
     //     and its K split for few, long items (same rule as launch_winograd).
     static int cus_dev[vfi::kMaxDevices] = {};
@@ -399,7 +400,7 @@ bool vfi::conv::winograd4_suits(const ConvArgs &a, int N) {
         cus = n;
     }
     const int nchunks = vfi::ceil_div(a.Cin, T::CK), cb = a.Cout_pad / T::BN;
-    const double cost4 = (double)((items + cus - 1) / cus) * (1.55 * nchunks + 5.0);
+    const double cost4 = (double)((items + cus - 1) / cus) * (1.45 * nchunks + 3.8);
     const long long items2 = (long long)vfi::ceil_div(a.W, 32) * vfi::ceil_div(a.H, 8) * N * cb, resident2 = 2ll * cus;
     const long long out_floats = (long long)N * a.Cout * a.H * a.W;
     auto cost2 = [&](int S) {

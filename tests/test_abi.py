@@ -80,6 +80,7 @@ def test_conv_algorithm_query_reports_the_library_rule():
     assert algo(3, 256, 136, 240, 256, 3, 0, 0, RELU) == 2         # 864 items (3.4 rounds) of 64 chunks: F(4x4) by 17 %
     assert algo(1, 128, 136, 240, 128, 3, 0, 0, RELU) == 2         # 144 items, one round: F(4x4) by 19 %
     assert algo(1, 64, 272, 480, 64, 3, 0, 0, RELU) == 1           # 272 items = 1.06 rounds: the second round is empty -> F(2x2)
+    assert algo(1, 128, 272, 480, 128, 3, 0, 0, RELU) == 2         # 544 items = 2.1 rounds of 32 chunks: F(4x4) by 12 % (F(2x2) before the cheaper item epilogue)
     assert algo(1, 512, 34, 60, 512, 3, 0, 0, RELU) == 1           # 48 long items: F(2x2) with its K split
     assert algo(3, 64, 68, 120, 64, 3, 0, 0, ELU) == 1             # small PhaseNet level
     assert algo(1, 32, 1088, 1920, 32, 3, 0, 1, RELU) == 2         # pooled ReLU layer: F(4x4) POOL instantiation

@@ -21,6 +21,8 @@ for spec in sys.argv[1:]:
     act = f[5] if len(f) > 5 else "elu"
     act = None if act == "none" else act
     res = torch.randn((n, cout, h, w), device=dev) if len(f) > 6 and f[6] == "res" else None
+    if len(f) > 6 and f[6] == "pool":
+        res = "pool"
     x = torch.randn((n, cin, h, w), device=dev)
     pc = ops.PackedConv(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5, torch.zeros(cout), device=dev)
     out = torch.empty((n, cout, h, w), device=dev)
@@ -30,7 +32,10 @@ for rnd in range(ROUNDS + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(LAUNCHES):
-            ops.conv2d(x, pc, "reflect", act, out=out, residual=res)
+            if res == "pool":
+                ops.conv2d_pool2(x, pc, False, "zeros", act)
+            else:
+                ops.conv2d(x, pc, "reflect", act, out=out, residual=res)
         e1.record()
         torch.cuda.synchronize()
         if rnd:
@@ -38,4 +43,4 @@ for rnd in range(ROUNDS + 1):
 for spec, n, cin, cout, h, w, act, x, pc, out, times, res in cases:
     gf = 2.0 * n * cin * cout * 36 * (h * w / 16) / 1e9
     lo, med = min(times), statistics.median(times)
-    print(f"N{n} {cin}->{cout} @{h}x{w} {act}{' +res' if res is not None else ''}: min {lo:.3f} ms ({gf / lo / 157.3:.3f})  median {med:.3f} ms ({gf / med / 157.3:.3f} of 157.3 TFLOP/s, F(4x4) count)")
+    print(f"N{n} {cin}->{cout} @{h}x{w} {act}{' +pool' if res == 'pool' else ' +res' if res is not None else ''}: min {lo:.3f} ms ({gf / lo / 157.3:.3f})  median {med:.3f} ms ({gf / med / 157.3:.3f} of 157.3 TFLOP/s, F(4x4) count)")
