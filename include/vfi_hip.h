@@ -17,7 +17,7 @@
  *     Workspace is caller-provided or owned by an explicit plan object.
  *   - Process-wide state is limited to idempotent per-device launch setup (the dynamic-LDS
  *     attribute of three kernels, the CU count), tuning switches read once from the
- *     environment (VFI_CONV_WINOGRAD, VFI_CONV_WINOGRAD4, VFI_ADACOF_VARIANT, VFI_ADACOF_MARGIN; VFI_CONV_WINOGRAD4M at every call) and the
+ *     environment (VFI_CONV_WINOGRAD, VFI_CONV_WINOGRAD4, VFI_CONV_STREAM1X1, VFI_ADACOF_VARIANT, VFI_ADACOF_MARGIN; VFI_CONV_WINOGRAD4M at every call) and the
  *     thread-local last-error string; everything else lives in explicit plan objects,
  *     whose tables are immutable after creation and whose workspace belongs to ONE stream
  *     at a time (frames in flight on different streams use different plans).
@@ -139,7 +139,9 @@ int vfi_conv2d_pack(const float *w_oihw, const float *scale, float *packed, int 
  * weights with folded BatchNorm).  Environment (A/B aids): VFI_CONV_WINOGRAD4=0 keeps F(2x2) everywhere, =2 sends every
  * plain 3x3 layer to F(4x4); VFI_CONV_WINOGRAD4M=0 (read at every call) runs F(4x4) on round 3's kernel -- 16 channels per
  * wave, two waves per SIMD; bit-identical outputs -- instead of the 32-channel-per-wave one; VFI_CONV_WINOGRAD=0 selects
- * the direct kernel.  KS = 1 / 5: the direct one.
+ * the direct kernel.  KS = 5: the direct one.  KS = 1: the direct one, except layers with at most 16 output channels on an even
+ * number of >= 4096 pixels without a residual (8-byte-aligned operands): a streaming kernel that reads the input once at the HBM
+ * rate (vector ALU, fp32 FMA chain over the input channels in order; VFI_CONV_STREAM1X1=0 keeps the direct kernel).
  *   x        (N, Cin, H, W); consecutive samples are x_bstride floats apart, so x may be a channel
  *            slice of a wider tensor (no concat / split copies)
  *   residual NULL or (N, Cout, H, W) with stride res_bstride, added AFTER the activation
