@@ -323,7 +323,7 @@ __global__ void phasenet_emit_kernel(const float *__restrict__ pred, long long p
         const float *pr = pred + (size_t)n * pred_bs + p;
         const float *am = amp_in + (size_t)n * amp_bs + p;
         const float beta = (pr[(size_t)(4 + b) * HW] + 1.0f) / 2.0f;
-        const float a = beta * am[(size_t)(4 + b) * HW] + (1.0f - beta) * am[(size_t)b * HW];
+        const float a = fmaf(beta, am[(size_t)(4 + b) * HW], (1.0f - beta) * am[(size_t)b * HW]);      // (spelled out: vfi_phasenet_predict computes the same bits)
         phase_out[i] = pr[(size_t)b * HW] * 3.14159265358979323846f;
         amp_out[i] = a * maxv[n];
     }

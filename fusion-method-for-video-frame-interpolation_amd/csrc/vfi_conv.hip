@@ -474,6 +474,81 @@ static int launch_conv1x1_stream(const ConvArgs &a, int N, hipStream_t s) {
     return vfi::check_launch("vfi_conv2d");
 }
 
+// ---- PhaseNet's prediction head of one level in one pass (phase_net.py:149-168, 190-207 + reverse_normalize :80-90): the
+// 64 -> 8 1x1 map with tanh (conv1x1_stream_kernel's loop), written out because the next level resizes it, and from the same
+// registers the level's outputs: phase = pred[0:4] * pi, amp = (b * amp_in[4:8] + (1 - b) * amp_in[0:4]) * max[n] with
+// b = (pred[4:8] + 1) / 2 -- vfi_phasenet_emit's arithmetic to the bit, without reading pred back.
+template <int VEC>
+__global__ __launch_bounds__(256) void phasenet_predict_kernel(const float *__restrict__ x, long long x_bs, const float *__restrict__ wp,
+                                                               const float *__restrict__ bias, int Cout_pad, const float *__restrict__ amp_in,
+                                                               long long amp_bs, const float *__restrict__ maxv, float *__restrict__ pred,
+                                                               long long pred_bs, float *__restrict__ phase_out, float *__restrict__ amp_out,
+                                                               int Cin, int HW) {
+    typedef float vec __attribute__((ext_vector_type(VEC)));
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q * VEC >= HW) return;
+    const int n = blockIdx.y;
+    const vec *xp = reinterpret_cast<const vec *>(x + (size_t)n * x_bs) + q;
+    const size_t plane = (size_t)HW / VEC;
+    float acc[8][VEC];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[o][k] = 0.0f;
+    int c = 0;
+    for (; c + 8 <= Cin; c += 8) {
+        vec v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = xp[(size_t)(c + i) * plane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float *w = wp + (size_t)(c + i) * Cout_pad;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const float wo = w[o];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[o][k] = fmaf(wo, v[i][k], acc[o][k]);
+            }
+        }
+    }
+    for (; c < Cin; ++c) {
+        const vec v = xp[(size_t)c * plane];
+        const float *w = wp + (size_t)c * Cout_pad;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float wo = w[o];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[o][k] = fmaf(wo, v[k], acc[o][k]);
+        }
+    }
+    vec *pp = reinterpret_cast<vec *>(pred + (size_t)n * pred_bs) + q;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const float b = bias ? bias[o] : 0.0f;
+        vec r;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[k] = acc[o][k] = apply_act(acc[o][k] + b, 3);
+        pp[(size_t)o * plane] = r;
+    }
+    const vec *ap = reinterpret_cast<const vec *>(amp_in + (size_t)n * amp_bs) + q;
+    vec *pho = reinterpret_cast<vec *>(phase_out + (size_t)n * 4 * HW) + q, *amo = reinterpret_cast<vec *>(amp_out + (size_t)n * 4 * HW) + q;
+    const float mx = maxv[n];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const vec a0 = ap[(size_t)b * plane], a1 = ap[(size_t)(4 + b) * plane];
+        vec ph, am;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float beta = (acc[4 + b][k] + 1.0f) / 2.0f;
+            const float a = fmaf(beta, a1[k], (1.0f - beta) * a0[k]);
+            ph[k] = acc[b][k] * 3.14159265358979323846f;
+            am[k] = a * mx;
+        }
+        pho[(size_t)b * plane] = ph;
+        amo[(size_t)b * plane] = am;
+    }
+}
+
 void vfi::conv::launch_splitk_reduce(const ConvArgs &b, int N, hipStream_t s) {
     const int HW = b.H * b.W;
     const bool vec = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(b.y) & 15u) == 0 && b.y_bs % 4 == 0 &&
@@ -620,6 +695,34 @@ extern "C" int vfi_conv2d(const float *x, long long x_bstride, const float *pack
                           long long workspace_floats, vfi_stream_t stream) {
     return conv2d_impl(x, x_bstride, packed_w, bias, residual, res_bstride, y, y_bstride, N, Cin, H, W, Cout, KS,
                        pad_mode, act, false, workspace, workspace_floats, stream);
+}
+
+extern "C" int vfi_phasenet_predict(const float *feat, long long feat_bstride, const float *packed_w, const float *bias,
+                                    const float *amp_in, long long amp_bstride, const float *max_amp, float *pred, long long pred_bstride,
+                                    float *phase_out, float *amp_out, int N, int Cin, int H, int W, vfi_stream_t stream) {
+    VFI_REQUIRE(feat && packed_w && amp_in && max_amp && pred && phase_out && amp_out, VFI_ERR_INVALID_ARG, "vfi_phasenet_predict: null pointer");
+    VFI_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && H > 0 && W > 0, VFI_ERR_INVALID_ARG, "vfi_phasenet_predict: bad sizes");
+    const long long HW = (long long)H * W;
+    VFI_REQUIRE((long long)Cin * HW < (1ll << 31), VFI_ERR_UNSUPPORTED, "vfi_phasenet_predict: per-sample tensor too large for 32-bit offsets");
+    ConvArgs a{};
+    a.x = feat; a.y = pred; a.x_bs = feat_bstride; a.y_bs = pred_bstride; a.Cout = 8; a.H = H; a.W = W;
+    int vec = conv1x1_stream_vec(a, 1);
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(amp_in) | reinterpret_cast<uintptr_t>(phase_out) | reinterpret_cast<uintptr_t>(amp_out) | (uintptr_t)(amp_bstride * 4);
+    if (vec == 4 && (bits & 15u)) vec = (bits & 7u) ? 0 : 2;
+    else if (vec == 2 && (bits & 7u)) vec = 0;
+    if (!vec) {        // small or odd levels: the two launches this entry point replaces
+        const int rc = conv2d_impl(feat, feat_bstride, packed_w, bias, nullptr, 0, pred, pred_bstride, N, Cin, H, W, 8, 1, 0, 3, false, nullptr, 0, stream);
+        return rc ? rc : vfi_phasenet_emit(pred, pred_bstride, amp_in, amp_bstride, max_amp, phase_out, amp_out, N, (int)HW, stream);
+    }
+    const dim3 grid((unsigned)vfi::ceil_div((int)(HW / vec), 256), (unsigned)N);
+    hipStream_t s = vfi::as_stream(stream);
+    if (vec == 4)
+        hipLaunchKernelGGL(phasenet_predict_kernel<4>, grid, dim3(256), 0, s, feat, feat_bstride, packed_w, bias, 32, amp_in, amp_bstride, max_amp, pred,
+                           pred_bstride, phase_out, amp_out, Cin, (int)HW);
+    else
+        hipLaunchKernelGGL(phasenet_predict_kernel<2>, grid, dim3(256), 0, s, feat, feat_bstride, packed_w, bias, 32, amp_in, amp_bstride, max_amp, pred,
+                           pred_bstride, phase_out, amp_out, Cin, (int)HW);
+    return vfi::check_launch("vfi_phasenet_predict");
 }
 
 extern "C" int vfi_conv2d_pool2(const float *x, long long x_bstride, const float *packed_w, const float *bias, float *y,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vfi_affine_slice": [c_f, c_l, c_f, c_l, c_i, c_l, c_f, c_fl, c_s],
     "vfi_batch_max": [c_f, c_l, c_i, c_l, c_fl, c_f, c_f, c_s],
     "vfi_phasenet_emit": [c_f, c_l, c_f, c_l, c_f, c_f, c_f, c_i, c_i, c_s],
+    "vfi_phasenet_predict": [c_f, c_l, c_f, c_f, c_f, c_l, c_f, c_f, c_l, c_f, c_f, c_i, c_i, c_i, c_i, c_s],
     "vfi_phasenet_emit_low": [c_f, c_l, c_f, c_l, c_f, c_f, c_i, c_i, c_s],
     "vfi_tanh_residual_clamp": [c_f, c_f, c_f, c_l, c_s],
     "vfi_rgb2lab": [c_f, c_f, c_i, c_i, c_s],

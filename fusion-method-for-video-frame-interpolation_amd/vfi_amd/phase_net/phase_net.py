@@ -138,7 +138,7 @@ class PhaseNet(PackedModule):
         b, _, hl, wl = low_in.shape
         stream = _lib.stream_ptr()
 
-        def block(i, x, fp, prev=None):
+        def block(i, x, fp, prev=None, head=True):
             c1, c2, cp = packed[i]
             mode = "reflect" if c1.ks == 3 else "zeros"
             if prev is not None:     # 3x3 block: the resize of (feature | prediction) is done by the conv's tile loader
@@ -146,7 +146,8 @@ class PhaseNet(PackedModule):
             else:
                 t = ops.conv2d(x, c1, mode, "elu")
             ops.conv2d(t, c2, mode, "elu", out=fp[:, :64])
-            ops.conv2d(fp[:, :64], cp, "zeros", "tanh", out=fp[:, 64:])
+            if head:                 # (the band levels' prediction map comes out of vfi_phasenet_predict with their outputs)
+                ops.conv2d(fp[:, :64], cp, "zeros", "tanh", out=fp[:, 64:])
             return fp
 
         fp = block(0, low_in, ops.new((b, 65, hl, wl), low_in))                       # :113
@@ -172,11 +173,17 @@ class PhaseNet(PackedModule):
             fused = packed[i][0].ks == 3 and (64 + p_prev) % 8 == 0
             if not fused:
                 ops.resize_bilinear(fp, (h, w), align_corners=False, out=x[:, :64 + p_prev])   # :138-141
-            fp = block(i, x, ops.new((b, 72, h, w), low_in), prev=fp if fused else None)
+            fp = block(i, x, ops.new((b, 72, h, w), low_in), prev=fp if fused else None, head=False)
             amp_in = x[:, 64 + p_prev + c:]
             p_out, a_out = ops.new((b * 4, 1, h, w), low_in), ops.new((b * 4, 1, h, w), low_in)
-            _lib.call("vfi_phasenet_emit", fp[:, 64:].data_ptr(), fp.stride(0), amp_in.data_ptr(), x.stride(0),
-                      self.max_amplitudes[idx].data_ptr(), p_out.data_ptr(), a_out.data_ptr(), b, h * w, stream)
+            # prediction map (1x1, tanh) + this level's outputs in one pass over the 64 feature channels (:149-168)
+            cp = packed[i][2]
+            if cp.cout != 8 or cp.ks != 1:
+                raise RuntimeError("PhaseNet: a band level's prediction map must be a 1x1 layer with 8 outputs (phase_net.py:30-35)")
+            _lib.call("vfi_phasenet_predict", fp.data_ptr(), fp.stride(0), cp.packed.data_ptr(), cp.bias.data_ptr(), amp_in.data_ptr(),
+                      x.stride(0), self.max_amplitudes[idx].data_ptr(), fp[:, 64:].data_ptr(), fp.stride(0), p_out.data_ptr(),
+                      a_out.data_ptr(), b, 64, h, w, stream,
+                      work=("byte", 4.0 * b * (64 + 8 + 8 + 8) * h * w, "phasenet_predict_kernel") if _lib.PROFILE is not None else None)
             phases.append(p_out); amps.append(a_out)
         for _ in range(self.pyr.height - 2 - m):                                           # :91-93
             phases.append(0); amps.append(0)

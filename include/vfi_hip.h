@@ -248,6 +248,14 @@ int vfi_batch_max(const float *x, long long x_bstride, int N, long long count, f
 int vfi_phasenet_emit(const float *pred, long long pred_bstride, const float *amp_in, long long amp_bstride,
                       const float *max_amp, float *phase_out, float *amp_out, int N, int HW, vfi_stream_t stream);
 
+/* The prediction head of one PhaseNet level in one pass (phase_net.py:149-168, 190-207): pred (N,8,H*W) = tanh(1x1 conv of feat
+ * (N,Cin,H*W) with packed_w / bias: the weights of vfi_conv2d_pack for Cout = 8, KS = 1), written out (the next level resizes
+ * it), and vfi_phasenet_emit's outputs from the same registers.  Same results as vfi_conv2d(act = tanh) followed by
+ * vfi_phasenet_emit, which is what small or odd-sized levels still run. */
+int vfi_phasenet_predict(const float *feat, long long feat_bstride, const float *packed_w, const float *bias,
+                         const float *amp_in, long long amp_bstride, const float *max_amp, float *pred, long long pred_bstride,
+                         float *phase_out, float *amp_out, int N, int Cin, int H, int W, vfi_stream_t stream);
+
 /* phase_net.py:113-116 + :96-98: low_out (N,HW) = (a*low_in[:,0] + (1-a)*low_in[:,1])*max_low[n], a = (pred+1)/2. */
 int vfi_phasenet_emit_low(const float *pred, long long pred_bstride, const float *low_in, long long low_bstride,
                           const float *max_low, float *low_out, int N, int HW, vfi_stream_t stream);

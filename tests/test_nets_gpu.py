@@ -162,3 +162,33 @@ def test_architecture_phasenet_image_in_image_out(device):
     # high_level=True copies the high residual of another prediction in
     pred_h, vals_h, _ = net(img.to(device), high_level=True, ada_pred=img[:3].to(device))
     assert vals_h.high_level.abs().max().item() > 0 and torch.isfinite(pred_h).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w", [(3, 96, 128), (2, 74, 83), (3, 9, 15), (1, 65, 67)])
+def test_phasenet_predict_equals_conv_then_emit(n, h, w, device):
+    """vfi_phasenet_predict (one pass: 1x1 tanh map + the level's outputs; phase_net.py:149-168) against the two calls it
+    replaces -- vfi_conv2d(act = tanh) and vfi_phasenet_emit -- on channel slices of the block buffers, streaming sizes (4 and 2
+    pixels per thread), a small level and an odd plane (both fall back to the two launches inside the library)."""
+    from vfi_amd import _lib, ops
+    g = torch.Generator().manual_seed(h * w + n)
+    fp = torch.randn((n, 72, h, w), generator=g).to(device)
+    x = torch.rand((n, 88, h, w), generator=g).to(device)
+    mx = (torch.rand((n,), generator=g) + 0.5).to(device)
+    pc = ops.PackedConv(torch.randn((8, 64, 1, 1), generator=g) / 8.0, torch.randn((8,), generator=g) * 0.1, device=device)
+    amp_in = x[:, 80:]
+    ref_fp = fp.clone()
+    ops.conv2d(ref_fp[:, :64], pc, "zeros", "tanh", out=ref_fp[:, 64:])
+    p_ref, a_ref = torch.empty((n, 4, h, w), device=device), torch.empty((n, 4, h, w), device=device)
+    _lib.call("vfi_phasenet_emit", ref_fp[:, 64:].data_ptr(), ref_fp.stride(0), amp_in.data_ptr(), x.stride(0), mx.data_ptr(),
+              p_ref.data_ptr(), a_ref.data_ptr(), n, h * w, _lib.stream_ptr())
+    p_out, a_out = torch.empty_like(p_ref), torch.empty_like(a_ref)
+    _lib.call("vfi_phasenet_predict", fp.data_ptr(), fp.stride(0), pc.packed.data_ptr(), pc.bias.data_ptr(), amp_in.data_ptr(), x.stride(0),
+              mx.data_ptr(), fp[:, 64:].data_ptr(), fp.stride(0), p_out.data_ptr(), a_out.data_ptr(), n, 64, h, w, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(fp[:, :64], ref_fp[:, :64])                       # the features are only read
+    if h * w >= 4096 and (h * w) % 2 == 0:      # the streaming kernels: the same FMA chain over the channels in both
+        assert torch.equal(fp[:, 64:], ref_fp[:, 64:]) and torch.equal(p_out, p_ref) and torch.equal(a_out, a_ref)
+    else:                                       # matrix-core kernel inside the library, without / with the caller's split-K workspace
+        for got, ref in ((fp[:, 64:], ref_fp[:, 64:]), (p_out, p_ref), (a_out, a_ref)):
+            assert (got - ref).abs().max().item() <= 2e-6
