@@ -124,6 +124,7 @@ def test_f4x4_kernel_on_small_and_ragged_shapes(device):
 @pytest.mark.parametrize("n,cin,cout,h,w,pad,act,variant", [
     (1, 64, 64, 272, 1920, "zeros", "relu", "plain"),       # the 1080p U-Net / PhaseNet shape class: 16 chunks per item
     (3, 64, 64, 100, 1920, "reflect", "elu", "residual"),   # PhaseNet block with its residual, ragged tile rows
+    (2, 64, 64, 132, 1920, "zeros", "relu", "residual"),    # decoder skip layer: the ReLU-specialised residual instantiation, residual rows requested one channel ahead
     (1, 28, 25, 544, 1920, "zeros", None, "plain"),         # head layer: 7 chunks (odd: both body parities end an item), Cout tail
     (2, 32, 64, 256, 1024, "zeros", "relu", "pool"),        # pooled second output
     (1, 16, 96, 512, 2048, "reflect", "tanh", "plain"),     # three channel blocks, 4 chunks: items shorter than the ring
